@@ -1,0 +1,109 @@
+/*
+ * pn2_hip.h -- C ABI of libpn2hip.so: the MI355X (gfx950) PointNet++ set-abstraction /
+ * feature-propagation hot path.
+ *
+ * The reference has no FFI layer for this path: the boundary it exposes is the Python module
+ * surface of models/pointnet2_utils.py.  Every entry point below replaces one
+ * torch-op composition of that file (cited per function) and is what a ctypes / cffi /
+ * pybind stub inside the reference's models/pointnet2_utils.py binds to.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller
+ *     (the library allocates nothing and keeps no global mutable state: reentrant);
+ *   - float tensors are fp32, index tensors int64, row-major contiguous, layouts as in the
+ *     reference's free functions: xyz [B,N,3], points [B,N,D], idx [B,S] / [B,S,K];
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     nothing synchronises, nothing allocates: every launcher is hipGraph-capture safe;
+ *   - return value: PN2_OK, a negative PN2_ERR_* for invalid arguments (nothing launched),
+ *     or a positive hipError_t from the launch;
+ *   - data-dependent faults (the reference raises IndexError, pointnet2_utils.py:59) are
+ *     counted into the caller's device word `err_count` (may be NULL): the host shim zeroes
+ *     it before and reads it after, lazily.
+ */
+#ifndef PN2_HIP_H
+#define PN2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_ABI_VERSION 1
+
+typedef void *pn2_stream_t; /* hipStream_t */
+
+enum {
+    PN2_OK = 0,
+    PN2_ERR_NULL = -1,        /* required pointer is NULL */
+    PN2_ERR_SHAPE = -2,       /* negative / zero / inconsistent size */
+    PN2_ERR_UNSUPPORTED = -3, /* size outside what the kernels are built for */
+};
+
+int pn2_abi_version(void);
+const char *pn2_error_string(int rc);
+
+/* farthest_point_sample(xyz, npoint)                     models/pointnet2_utils.py:63-84
+ * start[B]: the indices the reference draws with torch.randint (:75), supplied by the caller.
+ * out_idx[B,npoint] int64.  new_xyz (nullable) [B,npoint,3] receives xyz[out_idx] -- the
+ * index_points call that always follows (:125) -- for free.
+ * Limits: 1 <= N <= 32768.  err_count += 1 per block whose start is outside [0,N). */
+int pn2_farthest_point_sample(const float *xyz, int B, int N, int npoint, const int64_t *start,
+                              int64_t *out_idx, float *new_xyz, int32_t *err_count, pn2_stream_t stream);
+
+/* square_distance(src, dst) -> out[B,N,M]                models/pointnet2_utils.py:19-40
+ * bit-for-bit the reference's CPU result (expansion form).  The other
+ * kernels evaluate the same expression in registers and never materialise this matrix. */
+int pn2_square_distance(const float *src, const float *dst, int B, int N, int M, float *out,
+                        pn2_stream_t stream);
+
+/* query_ball_point(radius, nsample, xyz, new_xyz) fused with the grouping half of
+ * sample_and_group                                      models/pointnet2_utils.py:87-107, 127-132
+ * idx[B,S,nsample] int64; grouped (nullable) [B,S,nsample,3+D] = [xyz[idx]-new_xyz, points[idx]];
+ * points nullable (then D must be 0).  A centroid with no point inside the radius
+ * (reference: IndexError at :59) gets idx = N, a zero grouped row block and err_count += 1.
+ * Limits: 1 <= nsample <= 64. */
+int pn2_ball_query_group(double radius, int nsample, const float *xyz, const float *new_xyz,
+                         const float *points, int B, int N, int S, int D, int64_t *idx, float *grouped,
+                         int32_t *err_count, pn2_stream_t stream);
+
+/* index_points(points, idx) -> out[B,M,C]                models/pointnet2_utils.py:43-60
+ * idx is [B,M] (any trailing idx dims flattened into M).  Out-of-range index: zero row,
+ * err_count += 1. */
+int pn2_index_points(const float *points, const int64_t *idx, int B, int N, int C, int64_t M, float *out,
+                     int32_t *err_count, pn2_stream_t stream);
+
+/* autograd of index_points w.r.t. points (scatter-add)    models/pointnet2_utils.py:59
+ * grad_points[B,N,D] += grad_out[B,M,Cg][:, :, col0:col0+D] at rows idx.  The caller zeroes
+ * grad_points first.  col0/Cg let the grouped tensor's gradient [B,S*K,3+D] be scattered
+ * without slicing (col0 = 3). */
+int pn2_index_points_backward(const float *grad_out, const int64_t *idx, int B, int N, int D, int64_t M,
+                              int Cg, int col0, float *grad_points, pn2_stream_t stream);
+
+/* grouping half of sample_and_group for a given idx      models/pointnet2_utils.py:127-132 */
+int pn2_group_points(const float *xyz, const float *new_xyz, const float *points, const int64_t *idx,
+                     int B, int N, int S, int K, int D, float *grouped, int32_t *err_count,
+                     pn2_stream_t stream);
+
+/* three nearest neighbours + inverse-distance weights of PointNetFeaturePropagation
+ *                                                       models/pointnet2_utils.py:296-302
+ * xyz1[B,N,3] queries, xyz2[B,S,3] sources, S >= 3.  idx3[B,N,3] int64 ascending distance
+ * (exact ties: lowest index first -- the reference's unstable sort leaves them unpinned),
+ * dist3 (nullable) the expansion-form distances, weight3[B,N,3]. */
+int pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int64_t *idx3, float *dist3,
+                 float *weight3, pn2_stream_t stream);
+
+/* interpolated[b,i,:] = sum_k points2[b,idx3[b,i,k],:] * weight3[b,i,k]
+ *                                                       models/pointnet2_utils.py:303 */
+int pn2_three_interpolate(const float *points2, const int64_t *idx3, const float *weight3, int B, int N,
+                          int S, int D, float *out, pn2_stream_t stream);
+
+/* autograd of :303 w.r.t. points2: grad_points2[B,S,D] (zeroed by the caller) +=
+ * weight3 * grad_out[B,N,D] at rows idx3. */
+int pn2_three_interpolate_backward(const float *grad_out, const int64_t *idx3, const float *weight3,
+                                   int B, int N, int S, int D, float *grad_points2, pn2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_HIP_H */

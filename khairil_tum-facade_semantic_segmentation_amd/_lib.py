@@ -1,0 +1,63 @@
+"""ctypes binding of libpn2hip.so (C ABI: include/pn2_hip.h).  No torch types cross it.
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent this
+module raises, and every operator in ops.py raises with it."""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libpn2hip.so")
+
+_vp, _ci, _cl, _cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+# name -> argtypes, in the order of include/pn2_hip.h
+SIGNATURES = {
+    "pn2_abi_version": [],
+    "pn2_error_string": [_ci],
+    "pn2_farthest_point_sample": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "pn2_square_distance": [_vp, _vp, _ci, _ci, _ci, _vp, _vp],
+    "pn2_ball_query_group": [_cd, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "pn2_index_points": [_vp, _vp, _ci, _ci, _ci, _cl, _vp, _vp, _vp],
+    "pn2_index_points_backward": [_vp, _vp, _ci, _ci, _ci, _cl, _ci, _ci, _vp, _vp],
+    "pn2_group_points": [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
+    "pn2_three_nn": [_vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "pn2_three_interpolate": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
+    "pn2_three_interpolate_backward": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
+}
+
+_lib = None
+
+
+class Pn2LibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpn2hip.so once.  Raises Pn2LibraryError if it was not built (run
+    `python __graft_entry__.py build` or the package's build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Pn2LibraryError(
+            "libpn2hip.so not found at %s: the HIP extension is not built and there is no CPU "
+            "fallback (build it with `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise Pn2LibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise Pn2LibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.argtypes = args
+        fn.restype = ctypes.c_char_p if name == "pn2_error_string" else _ci
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pn2_error_string(rc)
+        raise RuntimeError("%s failed: rc=%d (%s)" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,78 @@
+// Shared device helpers for libpn2hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pn2_hip.h"
+
+#pragma clang fp contract(off)
+
+#define PN2_EXPORT extern "C" __attribute__((visibility("default")))
+#define PN2_WAVE 64
+
+#define PN2_REQUIRE_PTR(p) \
+    do { if ((p) == nullptr) return PN2_ERR_NULL; } while (0)
+#define PN2_LAUNCH_RC() ((int)hipGetLastError())
+
+namespace pn2 {
+
+// |p|^2 exactly as torch.sum(p ** 2, -1) evaluates it: ((x*x + y*y) + z*z), every op rounded
+// (reference models/pointnet2_utils.py:38-39; rule SURVEY.md 8a-2).
+__device__ __forceinline__ float norm3(float x, float y, float z)
+{
+    float xx = x * x;
+    float yy = y * y;
+    float zz = z * z;
+    return (xx + yy) + zz;
+}
+
+// square_distance(src=a, dst=b) for one pair, bit-for-bit the reference CPU result
+// (models/pointnet2_utils.py:37-39): dot is a k-ordered fma chain (sgemm with K=3), then
+// (-2*dot + |a|^2) + |b|^2.  -2*dot is exact, so fma(-2,dot,na) rounds once like the add does.
+__device__ __forceinline__ float pair_sqdist(float ax, float ay, float az, float na,
+                                             float bx, float by, float bz, float nb)
+{
+    float dot = __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+    float d = __builtin_fmaf(-2.0f, dot, na);
+    return d + nb;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (PN2_WAVE - 1)); }
+
+// 64-lane prefix popcount of a ballot mask (number of set bits below this lane).
+__device__ __forceinline__ int mbcnt(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+
+// max over the 64 lanes of a signed int, result uniform in every lane.
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x141>(v));  // row_half_mirror
+    v = max(v, dpp_i32<0x140>(v));  // row_mirror: every lane now holds its 16-lane row max
+    int r0 = __builtin_amdgcn_readlane(v, 0);
+    int r1 = __builtin_amdgcn_readlane(v, 16);
+    int r2 = __builtin_amdgcn_readlane(v, 32);
+    int r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// Bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md T1): workgroups that share
+// `id % 8` (one XCD under round-robin dispatch) get a contiguous range of logical ids, so that
+// workgroups working on the same 4096-point block hit the same L2.  Speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = id & 7u, k = id >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + k;
+}
+
+}  // namespace pn2

@@ -1,0 +1,144 @@
+// farthest_point_sample on gfx950.  Replaces the npoint-iteration torch loop of the reference
+// (models/pointnet2_utils.py:63-84): one workgroup per 4096-point block, the points and their
+// running min-distance live in registers for the whole kernel, one workgroup barrier per
+// iteration.  Latency-bound by construction (npoint dependent argmax steps); see DESIGN.md.
+#include "pn2_common.h"
+
+namespace {
+
+// T threads, P consecutive points per thread (thread t owns points t*P .. t*P+P-1, so lane
+// order == index order and "first lane with the max" == "lowest index with the max", the tie
+// rule of torch.max (:83)).
+template <int T, int P, bool LDS_XYZ>
+__global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
+                                                const int64_t *__restrict__ start,
+                                                int64_t *__restrict__ out_idx, float *__restrict__ new_xyz,
+                                                int32_t *err_count)
+{
+    constexpr int W = T / PN2_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(smem);     // [2][W]
+    float4 *pts = reinterpret_cast<float4 *>(smem + 2 * 16 * sizeof(unsigned long long));  // [T*P] if LDS_XYZ
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (PN2_WAVE - 1);
+    const int wave = tid / PN2_WAVE;
+    const float *p = xyz + (size_t)b * N * 3;
+
+    float px[P], py[P], pz[P], md[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int j = tid * P + k;
+        const bool in = j < N;
+        px[k] = in ? p[j * 3 + 0] : 0.0f;
+        py[k] = in ? p[j * 3 + 1] : 0.0f;
+        pz[k] = in ? p[j * 3 + 2] : 0.0f;
+        md[k] = in ? 1e10f : -1.0f;          // :74; padding can never be the max (real values >= 0)
+        if (LDS_XYZ) pts[j] = make_float4(px[k], py[k], pz[k], 0.0f);
+    }
+
+    long long far = start[b];                // :75 (drawn by the caller)
+    if (far < 0 || far >= N) {
+        if (tid == 0 && err_count) atomicAdd(err_count, 1);
+        far = 0;
+    }
+    if (LDS_XYZ) __syncthreads();
+
+    for (int i = 0; i < npoint; ++i) {
+        float cx, cy, cz;
+        if (LDS_XYZ) {
+            const float4 c = pts[far];
+            cx = c.x; cy = c.y; cz = c.z;
+        } else {
+            cx = p[far * 3 + 0]; cy = p[far * 3 + 1]; cz = p[far * 3 + 2];
+        }
+        if (tid == 0) {
+            out_idx[(size_t)b * npoint + i] = far;                               // :78
+            if (new_xyz) {
+                float *o = new_xyz + ((size_t)b * npoint + i) * 3;
+                o[0] = cx; o[1] = cy; o[2] = cz;
+            }
+        }
+        if (i + 1 == npoint) break;
+
+        int best = __float_as_int(-1.0f);
+        int bestj = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+            const float d = (dx * dx + dy * dy) + dz * dz;                       // :80, un-fused
+            md[k] = d < md[k] ? d : md[k];                                       // :81-82
+            // non-negative floats (and the -1 padding) order like their bit patterns as signed ints
+            const int bits = __float_as_int(md[k]);
+            if (bits > best) { best = bits; bestj = tid * P + k; }               // strict: lowest k wins
+        }
+        const int wmax = pn2::wave_max_i32(best);
+        const unsigned long long m = __ballot(best == wmax);
+        const int wl = __builtin_ctzll(m);
+        int widx = __builtin_amdgcn_readlane(bestj, wl);
+        if (W > 1) {
+            unsigned long long *s = slot + (i & 1) * W;
+            if (lane == 0) s[wave] = ((unsigned long long)(unsigned)wmax << 32) | (unsigned)widx;
+            __syncthreads();
+            const unsigned long long e = s[lane & (W - 1)];
+            const int ev = (int)(e >> 32);
+            const int gmax = pn2::wave_max_i32(ev);
+            const unsigned long long gm = __ballot(ev == gmax);
+            const int gl = __builtin_ctzll(gm);                                  // lowest wave == lowest index
+            widx = __builtin_amdgcn_readlane((int)(unsigned)e, gl);
+        }
+        far = widx;                                                              // :83
+    }
+}
+
+template <int T, int P>
+int launch_fps(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out_idx,
+               float *new_xyz, int32_t *err_count, hipStream_t stream)
+{
+    const size_t slots = 2 * 16 * sizeof(unsigned long long);
+    const bool lds_xyz = (size_t)T * P * sizeof(float4) <= 128 * 1024;
+    if (lds_xyz) {
+        const size_t lds = slots + (size_t)T * P * sizeof(float4);
+        auto k = fps_kernel<T, P, true>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(k, dim3(B), dim3(T), lds, stream, xyz, N, npoint, start, out_idx, new_xyz, err_count);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(B), dim3(T), slots, stream, xyz, N, npoint, start,
+                           out_idx, new_xyz, err_count);
+    }
+    return PN2_LAUNCH_RC();
+}
+
+}  // namespace
+
+PN2_EXPORT int pn2_farthest_point_sample(const float *xyz, int B, int N, int npoint, const int64_t *start,
+                                         int64_t *out_idx, float *new_xyz, int32_t *err_count,
+                                         pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(xyz);
+    PN2_REQUIRE_PTR(start);
+    PN2_REQUIRE_PTR(out_idx);
+    if (B < 0 || N <= 0 || npoint < 0) return PN2_ERR_SHAPE;
+    if (N > 32768) return PN2_ERR_UNSUPPORTED;
+    if (B == 0 || npoint == 0) return PN2_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define PN2_FPS_CASE(T, P) \
+    if (N <= (T) * (P)) return launch_fps<T, P>(xyz, B, N, npoint, start, out_idx, new_xyz, err_count, stream)
+    PN2_FPS_CASE(64, 1);
+    PN2_FPS_CASE(64, 2);
+    PN2_FPS_CASE(64, 4);
+    PN2_FPS_CASE(128, 4);
+    PN2_FPS_CASE(256, 4);
+    PN2_FPS_CASE(512, 4);
+    PN2_FPS_CASE(512, 8);
+    PN2_FPS_CASE(1024, 8);
+    PN2_FPS_CASE(1024, 16);
+    PN2_FPS_CASE(1024, 32);
+#undef PN2_FPS_CASE
+    return PN2_ERR_UNSUPPORTED;
+}

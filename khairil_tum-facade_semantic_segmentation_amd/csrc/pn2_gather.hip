@@ -1,0 +1,164 @@
+// index_points / grouping gathers, their scatter-add backward, and the materialising
+// square_distance, on gfx950.  Reference: models/pointnet2_utils.py:43-60 (advanced indexing),
+// :127-132 (grouping), :19-40 (square_distance).  All HBM-bound streaming kernels: lanes run
+// along the contiguous channel axis so every wave-instruction touches whole rows.
+#include "pn2_common.h"
+
+namespace {
+
+inline unsigned grid_for(long long total, int threads)
+{
+    long long blocks = (total + threads - 1) / threads;
+    const long long cap = 256LL * 16;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+__global__ __launch_bounds__(256) void index_points_kernel(const float *__restrict__ points,
+                                                           const int64_t *__restrict__ idx, long long total,
+                                                           int N, int C, long long M, float *__restrict__ out,
+                                                           int32_t *err_count)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / C;                   // b*M + m
+        const int c = (int)(t - row * C);
+        const long long b = row / M;
+        const int64_t j = idx[row];
+        float v = 0.0f;
+        if (j >= 0 && j < N) v = points[((size_t)b * N + j) * C + c];
+        else if (c == 0 && err_count) atomicAdd(err_count, 1);
+        out[t] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void index_points_backward_kernel(const float *__restrict__ grad_out,
+                                                                    const int64_t *__restrict__ idx,
+                                                                    long long total, int N, int D, long long M,
+                                                                    int Cg, int col0, float *__restrict__ grad_points)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / D;
+        const int c = (int)(t - row * D);
+        const long long b = row / M;
+        const int64_t j = idx[row];
+        if (j < 0 || j >= N) continue;
+        atomicAdd(grad_points + ((size_t)b * N + j) * D + c, grad_out[(size_t)row * Cg + col0 + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void group_points_kernel(const float *__restrict__ xyz,
+                                                           const float *__restrict__ new_xyz,
+                                                           const float *__restrict__ points,
+                                                           const int64_t *__restrict__ idx, long long total, int N,
+                                                           int S, int K, int D, float *__restrict__ grouped,
+                                                           int32_t *err_count)
+{
+    const int Cg = 3 + D;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / Cg;                  // (b*S + s)*K + k
+        const int c = (int)(t - row * Cg);
+        const long long bs = row / K;
+        const long long b = bs / S;
+        const int64_t j = idx[row];
+        float v = 0.0f;
+        if (j >= 0 && j < N) {
+            if (c < 3) v = xyz[((size_t)b * N + j) * 3 + c] - new_xyz[(size_t)bs * 3 + c];   // :128
+            else v = points[((size_t)b * N + j) * D + (c - 3)];                              // :131-132
+        } else if (c == 0 && err_count) atomicAdd(err_count, 1);
+        grouped[t] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ dst, long long total,
+                                                              int N, int M, float *__restrict__ out)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / M;                   // b*N + i
+        const int j = (int)(t - row * M);
+        const long long b = row / N;
+        const float *a = src + (size_t)row * 3;
+        const float *q = dst + ((size_t)b * M + j) * 3;
+        out[t] = pn2::pair_sqdist(a[0], a[1], a[2], pn2::norm3(a[0], a[1], a[2]), q[0], q[1], q[2],
+                                  pn2::norm3(q[0], q[1], q[2]));
+    }
+}
+
+}  // namespace
+
+PN2_EXPORT int pn2_abi_version(void) { return PN2_ABI_VERSION; }
+
+PN2_EXPORT const char *pn2_error_string(int rc)
+{
+    switch (rc) {
+        case PN2_OK: return "ok";
+        case PN2_ERR_NULL: return "required pointer is NULL";
+        case PN2_ERR_SHAPE: return "invalid or inconsistent size";
+        case PN2_ERR_UNSUPPORTED: return "size outside the supported range";
+        default: return rc > 0 ? hipGetErrorString((hipError_t)rc) : "unknown pn2 error";
+    }
+}
+
+PN2_EXPORT int pn2_index_points(const float *points, const int64_t *idx, int B, int N, int C, int64_t M, float *out,
+                                int32_t *err_count, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(points);
+    PN2_REQUIRE_PTR(idx);
+    PN2_REQUIRE_PTR(out);
+    if (B < 0 || N <= 0 || C <= 0 || M < 0) return PN2_ERR_SHAPE;
+    const long long total = (long long)B * M * C;
+    if (total == 0) return PN2_OK;
+    hipLaunchKernelGGL(index_points_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), points, idx, total, N, C, (long long)M, out, err_count);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_index_points_backward(const float *grad_out, const int64_t *idx, int B, int N, int D, int64_t M,
+                                         int Cg, int col0, float *grad_points, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(grad_out);
+    PN2_REQUIRE_PTR(idx);
+    PN2_REQUIRE_PTR(grad_points);
+    if (B < 0 || N <= 0 || D <= 0 || M < 0 || col0 < 0 || col0 + D > Cg) return PN2_ERR_SHAPE;
+    const long long total = (long long)B * M * D;
+    if (total == 0) return PN2_OK;
+    hipLaunchKernelGGL(index_points_backward_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), grad_out, idx, total, N, D, (long long)M, Cg, col0,
+                       grad_points);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_group_points(const float *xyz, const float *new_xyz, const float *points, const int64_t *idx,
+                                int B, int N, int S, int K, int D, float *grouped, int32_t *err_count,
+                                pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(xyz);
+    PN2_REQUIRE_PTR(new_xyz);
+    PN2_REQUIRE_PTR(idx);
+    PN2_REQUIRE_PTR(grouped);
+    if (B < 0 || N <= 0 || S <= 0 || K <= 0 || D < 0) return PN2_ERR_SHAPE;
+    if (D > 0 && points == nullptr) return PN2_ERR_NULL;
+    const long long total = (long long)B * S * K * (3 + D);
+    if (total == 0) return PN2_OK;
+    hipLaunchKernelGGL(group_points_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), xyz, new_xyz, points, idx, total, N, S, K, D, grouped,
+                       err_count);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_square_distance(const float *src, const float *dst, int B, int N, int M, float *out,
+                                   pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(src);
+    PN2_REQUIRE_PTR(dst);
+    PN2_REQUIRE_PTR(out);
+    if (B < 0 || N <= 0 || M <= 0) return PN2_ERR_SHAPE;
+    const long long total = (long long)B * N * M;
+    if (total == 0) return PN2_OK;
+    hipLaunchKernelGGL(square_distance_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), src, dst, total, N, M, out);
+    return PN2_LAUNCH_RC();
+}

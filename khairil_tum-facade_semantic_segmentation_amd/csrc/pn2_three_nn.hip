@@ -1,0 +1,228 @@
+// three-NN search + inverse-distance weights, interpolation and its backward, on gfx950.
+// Reference: PointNetFeaturePropagation.forward, models/pointnet2_utils.py:296-303 -- a full
+// [B,N,S] distance matrix plus a full sort per row to pick 3 entries.  Here each lane owns one
+// query point, the S sources are staged once in LDS (xyz + |p|^2) and streamed past it; the
+// S range is split over the 4 waves of a workgroup and the partial top-3 lists are merged in
+// range order, so exact ties resolve to the lowest index.
+#include <math.h>
+
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int NN_THREADS = 256;
+constexpr int NN_WAVES = NN_THREADS / PN2_WAVE;     // S split
+constexpr int NN_TILE = 2048;                       // sources per LDS pass (32 KiB)
+
+struct Top3 {
+    float d0, d1, d2;
+    int i0, i1, i2;
+};
+
+__device__ __forceinline__ void top3_insert(Top3 &t, float d, int j)
+{
+    // strict '<': an equal distance never displaces an earlier (lower) index
+    if (d < t.d2) {
+        if (d < t.d1) {
+            t.d2 = t.d1; t.i2 = t.i1;
+            if (d < t.d0) { t.d1 = t.d0; t.i1 = t.i0; t.d0 = d; t.i0 = j; }
+            else { t.d1 = d; t.i1 = j; }
+        } else { t.d2 = d; t.i2 = j; }
+    }
+}
+
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int S, int qtiles,
+    int64_t *__restrict__ idx3, float *__restrict__ dist3, float *__restrict__ weight3)
+{
+    __shared__ __attribute__((aligned(16))) float4 src[NN_TILE];
+    __shared__ float md[NN_WAVES][3][PN2_WAVE];
+    __shared__ int mi[NN_WAVES][3][PN2_WAVE];
+
+    const unsigned logical = pn2::xcd_remap(blockIdx.x, gridDim.x);
+    const int b = (int)(logical / (unsigned)qtiles);
+    const int qt = (int)(logical % (unsigned)qtiles);
+    const int tid = threadIdx.x;
+    const int lane = tid & (PN2_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / PN2_WAVE);
+    const int q = qt * PN2_WAVE + lane;                    // query handled by this lane (all 4 waves)
+    const float *b1 = xyz1 + (size_t)b * N * 3;
+    const float *b2 = xyz2 + (size_t)b * S * 3;
+
+    const int qq = min(q, N - 1);
+    const float ax = b1[qq * 3 + 0], ay = b1[qq * 3 + 1], az = b1[qq * 3 + 2];
+    const float na = pn2::norm3(ax, ay, az);
+    Top3 t = {INFINITY, INFINITY, INFINITY, 0, 0, 0};
+
+    for (int s0 = 0; s0 < S; s0 += NN_TILE) {
+        if (s0) __syncthreads();
+        const int ns = min(NN_TILE, S - s0);
+        for (int j = tid; j < ns; j += NN_THREADS) {
+            const float x = b2[(size_t)(s0 + j) * 3 + 0], y = b2[(size_t)(s0 + j) * 3 + 1],
+                        z = b2[(size_t)(s0 + j) * 3 + 2];
+            src[j] = make_float4(x, y, z, pn2::norm3(x, y, z));
+        }
+        __syncthreads();
+        // wave w scans the w-th contiguous quarter of this tile
+        const int per = (ns + NN_WAVES - 1) / NN_WAVES;
+        const int jb = wave * per, je = min(ns, jb + per);
+        for (int j = jb; j < je; ++j) {
+            const float4 p = src[j];                                             // LDS broadcast
+            // src = xyz1 (query), dst = xyz2 (source): pointnet2_utils.py:296
+            const float d = pn2::pair_sqdist(ax, ay, az, na, p.x, p.y, p.z, p.w);
+            if (__ballot(d < t.d2)) top3_insert(t, d, s0 + j);
+        }
+    }
+    md[wave][0][lane] = t.d0; md[wave][1][lane] = t.d1; md[wave][2][lane] = t.d2;
+    mi[wave][0][lane] = t.i0; mi[wave][1][lane] = t.i1; mi[wave][2][lane] = t.i2;
+    __syncthreads();
+    if (wave != 0 || q >= N) return;
+    // Merge in ascending source-range order.  With several LDS tiles the ranges interleave
+    // (wave w holds quarter w of every tile), so order candidates by (distance, index).
+    Top3 r = {INFINITY, INFINITY, INFINITY, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+    for (int w = 0; w < NN_WAVES; ++w) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = md[w][k][lane];
+            const int j = mi[w][k][lane];
+            const bool lt2 = d < r.d2 || (d == r.d2 && j < r.i2);
+            if (lt2 && d < INFINITY) {
+                const bool lt1 = d < r.d1 || (d == r.d1 && j < r.i1);
+                const bool lt0 = d < r.d0 || (d == r.d0 && j < r.i0);
+                if (lt1) {
+                    r.d2 = r.d1; r.i2 = r.i1;
+                    if (lt0) { r.d1 = r.d0; r.i1 = r.i0; r.d0 = d; r.i0 = j; }
+                    else { r.d1 = d; r.i1 = j; }
+                } else { r.d2 = d; r.i2 = j; }
+            }
+        }
+    }
+    const size_t o = ((size_t)b * N + q) * 3;
+    idx3[o] = r.i0; idx3[o + 1] = r.i1; idx3[o + 2] = r.i2;
+    if (dist3) { dist3[o] = r.d0; dist3[o + 1] = r.d1; dist3[o + 2] = r.d2; }
+    const float r0 = 1.0f / (r.d0 + 1e-8f);                                      // :300
+    const float r1 = 1.0f / (r.d1 + 1e-8f);
+    const float r2 = 1.0f / (r.d2 + 1e-8f);
+    const float nrm = (r0 + r1) + r2;                                            // :301
+    weight3[o] = r0 / nrm; weight3[o + 1] = r1 / nrm; weight3[o + 2] = r2 / nrm;  // :302
+}
+
+// out[b,i,:] = (p0*w0 + p1*w1) + p2*w2, one thread per VEC consecutive channels.
+template <int VEC>
+__global__ __launch_bounds__(256) void three_interpolate_kernel(
+    const float *__restrict__ points2, const int64_t *__restrict__ idx3, const float *__restrict__ weight3,
+    long long total, int N, int S, int D, float *__restrict__ out)
+{
+    const int dv = D / VEC;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / dv;                  // b*N + i
+        const int c = (int)(t - row * dv) * VEC;
+        const long long b = row / N;
+        const int64_t j0 = idx3[row * 3], j1 = idx3[row * 3 + 1], j2 = idx3[row * 3 + 2];
+        const float w0 = weight3[row * 3], w1 = weight3[row * 3 + 1], w2 = weight3[row * 3 + 2];
+        const float *p0 = points2 + ((size_t)b * S + j0) * D + c;
+        const float *p1 = points2 + ((size_t)b * S + j1) * D + c;
+        const float *p2 = points2 + ((size_t)b * S + j2) * D + c;
+        float *o = out + (size_t)row * D + c;
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(p0);
+            const float4 bb = *reinterpret_cast<const float4 *>(p1);
+            const float4 cc = *reinterpret_cast<const float4 *>(p2);
+            float4 r;
+            r.x = (a.x * w0 + bb.x * w1) + cc.x * w2;
+            r.y = (a.y * w0 + bb.y * w1) + cc.y * w2;
+            r.z = (a.z * w0 + bb.z * w1) + cc.z * w2;
+            r.w = (a.w * w0 + bb.w * w1) + cc.w * w2;
+            *reinterpret_cast<float4 *>(o) = r;
+        } else {
+            o[0] = (p0[0] * w0 + p1[0] * w1) + p2[0] * w2;
+        }
+    }
+}
+
+// grad_points2[b, idx3[b,i,k], c] += w_k * grad_out[b,i,c]; lanes run along c so that each
+// atomic wave-instruction covers contiguous bytes of one row (MI355X_MICROARCH float atomics).
+__global__ __launch_bounds__(256) void three_interpolate_backward_kernel(
+    const float *__restrict__ grad_out, const int64_t *__restrict__ idx3, const float *__restrict__ weight3,
+    long long total, int N, int S, int D, float *__restrict__ grad_points2)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / D;
+        const int c = (int)(t - row * D);
+        const long long b = row / N;
+        const float g = grad_out[t];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t j = idx3[row * 3 + k];
+            atomicAdd(grad_points2 + ((size_t)b * S + j) * D + c, g * weight3[row * 3 + k]);
+        }
+    }
+}
+
+inline unsigned grid_for(long long total, int threads)
+{
+    long long blocks = (total + threads - 1) / threads;
+    const long long cap = 256LL * 16;                  // grid-stride beyond 16 blocks per CU
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+}  // namespace
+
+PN2_EXPORT int pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int64_t *idx3,
+                            float *dist3, float *weight3, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(xyz1);
+    PN2_REQUIRE_PTR(xyz2);
+    PN2_REQUIRE_PTR(idx3);
+    PN2_REQUIRE_PTR(weight3);
+    if (B < 0 || N <= 0 || S < 3) return PN2_ERR_SHAPE;
+    if (B == 0) return PN2_OK;
+    const int qtiles = (N + PN2_WAVE - 1) / PN2_WAVE;
+    const long long nwg = (long long)B * qtiles;
+    if (nwg > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)nwg), dim3(NN_THREADS), 0,
+                       static_cast<hipStream_t>(stream_), xyz1, xyz2, N, S, qtiles, idx3, dist3, weight3);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_three_interpolate(const float *points2, const int64_t *idx3, const float *weight3, int B,
+                                     int N, int S, int D, float *out, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(points2);
+    PN2_REQUIRE_PTR(idx3);
+    PN2_REQUIRE_PTR(weight3);
+    PN2_REQUIRE_PTR(out);
+    if (B < 0 || N <= 0 || S <= 0 || D <= 0) return PN2_ERR_SHAPE;
+    if (B == 0) return PN2_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(points2) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    if (vec4) {
+        const long long total = (long long)B * N * (D / 4);
+        hipLaunchKernelGGL(three_interpolate_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, stream, points2,
+                           idx3, weight3, total, N, S, D, out);
+    } else {
+        const long long total = (long long)B * N * D;
+        hipLaunchKernelGGL(three_interpolate_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, stream, points2,
+                           idx3, weight3, total, N, S, D, out);
+    }
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_three_interpolate_backward(const float *grad_out, const int64_t *idx3, const float *weight3,
+                                              int B, int N, int S, int D, float *grad_points2,
+                                              pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(grad_out);
+    PN2_REQUIRE_PTR(idx3);
+    PN2_REQUIRE_PTR(weight3);
+    PN2_REQUIRE_PTR(grad_points2);
+    if (B < 0 || N <= 0 || S <= 0 || D <= 0) return PN2_ERR_SHAPE;
+    if (B == 0) return PN2_OK;
+    const long long total = (long long)B * N * D;
+    hipLaunchKernelGGL(three_interpolate_backward_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), grad_out, idx3, weight3, total, N, S, D, grad_points2);
+    return PN2_LAUNCH_RC();
+}

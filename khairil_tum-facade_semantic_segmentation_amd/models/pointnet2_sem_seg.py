@@ -1,0 +1,54 @@
+"""pointnet2_sem_seg on the HIP operator surface.
+
+Mirror of the reference's models/pointnet2_sem_seg.py:6-50 (the caller of the hot path, SURVEY.md
+8a-8): same constructor, same submodule names (=> identical state_dict keys), same outputs
+(log-probabilities [B,N,classes], l4 features [B,512,16]).  Activations stay channel-last
+between levels so no tensor is re-laid-out on the way through the network."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction
+
+# (npoint, radius, nsample, mlp) per set-abstraction level; reference :9-12
+SA_LEVELS = ((1024, 0.1, 32, (32, 32, 64)), (256, 0.2, 32, (64, 64, 128)),
+             (64, 0.4, 32, (128, 128, 256)), (16, 0.8, 32, (256, 256, 512)))
+# (name, in_channel, mlp) per feature-propagation level; reference :13-16
+FP_LEVELS = (("fp4", 768, (256, 256)), ("fp3", 384, (256, 256)), ("fp2", 320, (256, 128)),
+             ("fp1", 128, (128, 128, 128)))
+
+
+class get_model(nn.Module):
+    def __init__(self, num_classes, num_extra_features):
+        super().__init__()
+        cin = 6 + 3 + num_extra_features                 # l0 features are the whole input incl. xyz (:23-26)
+        for i, (npoint, radius, nsample, mlp) in enumerate(SA_LEVELS, start=1):
+            setattr(self, "sa%d" % i, PointNetSetAbstraction(npoint, radius, nsample, cin, list(mlp), False))
+            cin = mlp[-1] + 3
+        for name, cin, mlp in FP_LEVELS:
+            setattr(self, name, PointNetFeaturePropagation(cin, list(mlp)))
+        self.conv1 = nn.Conv1d(128, 128, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.drop1 = nn.Dropout(0.5)
+        self.conv2 = nn.Conv1d(128, num_classes, 1)
+
+    def forward(self, xyz):
+        """xyz [B, 3+3+extra, N] -> (log_softmax [B,N,classes], l4_points [B,512,16])."""
+        pts = xyz.permute(0, 2, 1).contiguous()          # [B,N,C]
+        geo = [pts[:, :, :3].contiguous()]
+        feat = [pts]
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            g, f = sa.forward_cl(geo[-1], feat[-1])
+            geo.append(g)
+            feat.append(f)
+        up = feat[4]
+        for lvl, fp in zip((3, 2, 1, 0), (self.fp4, self.fp3, self.fp2, self.fp1)):
+            up = fp.forward_cl(geo[lvl], geo[lvl + 1], feat[lvl] if lvl else None, up)   # :31-34
+        h = up.permute(0, 2, 1)
+        h = self.drop1(F.relu(self.bn1(self.conv1(h))))  # :36
+        h = F.log_softmax(self.conv2(h), dim=1)          # :37-38
+        return h.permute(0, 2, 1), feat[4].permute(0, 2, 1)
+
+
+class get_loss(nn.Module):                               # reference :44-50
+    def forward(self, pred, target, trans_feat, weight):
+        return F.nll_loss(pred, target, weight=weight)

@@ -1,0 +1,196 @@
+"""Drop-in operator surface for the reference's models/pointnet2_utils.py, backed by the
+gfx950 HIP library (include/pn2_hip.h).
+
+Same names, argument order, tensor layouts ([B,N,C] for free functions, [B,C,N] for modules),
+dtypes (int64 indices) and state_dict keys as the reference file, so models/pointnet2_sem_seg.py
+and checkpoints written by either implementation are interchangeable.  What differs is how the
+work is done: no [B,S,N] distance matrix, no sort, no python FPS loop -- see csrc/.
+
+Reference lines cited per symbol; `start=` / fps_starts() expose the FPS start indices the
+reference draws internally with torch.randint (:75)."""
+import contextlib
+from time import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+_FPS_START_QUEUE = []
+
+
+@contextlib.contextmanager
+def fps_starts(starts):
+    """Inject FPS start indices: each farthest_point_sample call inside the block pops one
+    [B] tensor from `starts` instead of drawing torch.randint (parity tests, reproducibility)."""
+    _FPS_START_QUEUE.extend(list(starts))
+    try:
+        yield
+    finally:
+        del _FPS_START_QUEUE[:]
+
+
+def _next_start(device):
+    if not _FPS_START_QUEUE:
+        return None
+    return torch.as_tensor(_FPS_START_QUEUE.pop(0), dtype=torch.long).to(device)
+
+
+def timeit(tag, t):                                     # reference :7-9
+    print("{}: {}s".format(tag, time() - t))
+    return time()
+
+
+def pc_normalize(pc):                                   # reference :11-17
+    pc = pc - np.mean(pc, axis=0)
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+
+
+def square_distance(src, dst):
+    """[B,N,3] x [B,M,3] -> [B,N,M], bit-identical to the reference's CPU result (:19-40)."""
+    return ops.square_distance(src, dst)
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] | [B,S,K] -> [B,S,(K,)C]  (:43-60); differentiable in points."""
+    return ops.index_points(points, idx)
+
+
+def farthest_point_sample(xyz, npoint, start=None):
+    """xyz [B,N,3] -> centroids [B,npoint] int64  (:63-84)."""
+    if start is None:
+        start = _next_start(xyz.device)
+    return ops.farthest_point_sample(xyz, npoint, start)
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """-> group_idx [B,S,nsample] int64: the nsample lowest indices within radius, tail padded
+    with the first (:87-107)."""
+    return ops.query_ball_point(radius, nsample, xyz, new_xyz)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start=None):
+    """-> new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D]  (:110-138)."""
+    if start is None:
+        start = _next_start(xyz.device)
+    fps_idx, new_xyz = ops.farthest_point_sample_with_xyz(xyz, npoint, start)
+    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points)
+    if returnfps:
+        grouped_xyz = ops.index_points(xyz, idx)
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """-> new_xyz [B,1,3] (zeros), new_points [B,1,N,3+D]  (:141-158)."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device, dtype=xyz.dtype)
+    grouped = xyz.reshape(B, 1, N, C)
+    if points is not None:
+        grouped = torch.cat([grouped, points.reshape(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped
+
+
+def _pointwise_mlp(x, convs, bns):
+    """[rows, Cin] -> [rows, Cout]: (1x1 conv -> BatchNorm -> ReLU) per layer on channel-last
+    rows.  The conv weights keep the reference's [Co,Ci,1(,1)] shapes; BN statistics run over
+    all rows, which is exactly BatchNorm2d over (B,K,S) / BatchNorm1d over (B,N)."""
+    for conv, bn in zip(convs, bns):
+        w = conv.weight.reshape(conv.weight.shape[0], -1)
+        x = torch.addmm(conv.bias, x, w.t()) if conv.bias is not None else x @ w.t()
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        x = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                         bn.training or not bn.track_running_stats,
+                         0.0 if bn.momentum is None else bn.momentum, bn.eps)
+        x = F.relu(x)
+    return x
+
+
+class PointNetSetAbstraction(nn.Module):                # reference :161-202
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        widths = [in_channel] + list(mlp)
+        for ci, co in zip(widths[:-1], widths[1:]):
+            self.mlp_convs.append(nn.Conv2d(ci, co, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(co))
+
+    def forward_cl(self, xyz, points, start=None):
+        """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C']."""
+        if self.group_all:
+            new_xyz, grouped = sample_and_group_all(xyz, points)
+        else:
+            new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)
+        B, S, K, C = grouped.shape
+        y = _pointwise_mlp(grouped.reshape(B * S * K, C), self.mlp_convs, self.mlp_bns)
+        return new_xyz, y.reshape(B, S, K, -1).max(dim=2)[0]
+
+    def forward(self, xyz, points):
+        """xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
+        new_xyz, feats = self.forward_cl(xyz.permute(0, 2, 1), None if points is None else points.permute(0, 2, 1))
+        return new_xyz.permute(0, 2, 1), feats.permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(nn.Module):             # reference :205-262
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super().__init__()
+        self.npoint, self.radius_list, self.nsample_list = npoint, radius_list, nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for mlp in mlp_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            widths = [in_channel + 3] + list(mlp)
+            for ci, co in zip(widths[:-1], widths[1:]):
+                convs.append(nn.Conv2d(ci, co, 1))
+                bns.append(nn.BatchNorm2d(co))
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward(self, xyz, points):
+        xyz = xyz.permute(0, 2, 1)
+        points = None if points is None else points.permute(0, 2, 1)
+        _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, self.npoint, _next_start(xyz.device))
+        scales = []
+        for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
+            _, g = ops.ball_query_group(radius, K, xyz, new_xyz, points)
+            if points is not None:                       # multi-scale variant orders [feats, xyz] (:248)
+                g = torch.cat([g[..., 3:], g[..., :3]], dim=-1)
+            B, S, _, C = g.shape
+            y = _pointwise_mlp(g.reshape(B * S * K, C), convs, bns)
+            scales.append(y.reshape(B, S, K, -1).max(dim=2)[0])
+        return new_xyz.permute(0, 2, 1), torch.cat(scales, dim=-1).permute(0, 2, 1)
+
+
+class PointNetFeaturePropagation(nn.Module):            # reference :265-315
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        widths = [in_channel] + list(mlp)
+        for ci, co in zip(widths[:-1], widths[1:]):
+            self.mlp_convs.append(nn.Conv1d(ci, co, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(co))
+
+    def forward_cl(self, xyz1, xyz2, points1, points2):
+        """Channel-last: xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,D1]|None, points2 [B,S,D2] -> [B,N,C']."""
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:                                      # :293-294
+            interpolated = points2.expand(B, N, points2.shape[-1])
+        else:
+            idx3, w3 = ops.three_nn(xyz1, xyz2)         # :296-302
+            interpolated = ops.three_interpolate(points2, idx3, w3)   # :303
+        x = interpolated if points1 is None else torch.cat([points1, interpolated], dim=-1)   # :305-309
+        y = _pointwise_mlp(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns)
+        return y.reshape(B, N, -1)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N]|None, points2 [B,D2,S] -> [B,D',N]."""
+        y = self.forward_cl(xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1),
+                            None if points1 is None else points1.permute(0, 2, 1), points2.permute(0, 2, 1))
+        return y.permute(0, 2, 1)

@@ -1,0 +1,307 @@
+"""Host-side operator layer: torch tensors in, libpn2hip.so (C ABI) underneath.
+
+torch is plumbing here (device memory, streams, autograd bookkeeping); every function below
+enqueues hand-written HIP kernels on torch's current stream through include/pn2_hip.h.  There is
+deliberately no CPU implementation: CPU tensors raise."""
+import torch
+
+from . import _lib
+
+_ERR = {}
+_ERROR_MODE = "lazy"
+
+
+def set_error_mode(mode):
+    """'eager': synchronise and raise IndexError right after an op that can fault (the
+    reference's behaviour, models/pointnet2_utils.py:59).  'lazy' (default): faults are
+    counted on the device and raised by check_errors()."""
+    global _ERROR_MODE
+    if mode not in ("lazy", "eager"):
+        raise ValueError(mode)
+    _ERROR_MODE = mode
+
+
+def _err_word(device):
+    key = (device.type, device.index)
+    t = _ERR.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _ERR[key] = t
+    return t
+
+
+def check_errors(device=None, what="pn2 op"):
+    """Raise IndexError if any kernel since the last check saw an empty ball / bad index."""
+    for key, t in list(_ERR.items()):
+        if device is not None and (device.type, device.index) != key:
+            continue
+        n = int(t.item())
+        if n:
+            t.zero_()
+            raise IndexError("%s: %d out-of-range index / empty ball-query neighbourhood(s) "
+                             "(the reference raises IndexError in index_points)" % (what, n))
+
+
+def _after_fault_op(device, what):
+    if _ERROR_MODE == "eager":
+        check_errors(device, what)
+
+
+def _dev(*tensors):
+    d = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("pn2 operators run on the HIP device only (got a %s tensor); there is "
+                               "no CPU fallback in the product path" % t.device)
+        if d is None:
+            d = t.device
+        elif t.device != d:
+            raise RuntimeError("tensors on different devices: %s vs %s" % (d, t.device))
+    return d
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _i64c(t):
+    return t.detach().to(torch.int64).contiguous()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------- sampling
+def farthest_point_sample_with_xyz(xyz, npoint, start=None):
+    """xyz [B,N,3] -> (idx [B,npoint] int64, new_xyz [B,npoint,3]).  `start` [B] are the start
+    indices; None draws them like the reference does (models/pointnet2_utils.py:75)."""
+    dev = _dev(xyz, start)
+    lib = _lib.load()
+    xyz = _f32c(xyz)
+    B, N, C = xyz.shape
+    if C != 3:
+        raise ValueError("xyz must be [B,N,3]")
+    if start is None:
+        start = torch.randint(0, N, (B,), dtype=torch.long, device=dev)
+    start = _i64c(start)
+    if start.shape != (B,):
+        raise ValueError("start must be [B]")
+    idx = torch.empty((B, npoint), dtype=torch.int64, device=dev)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_farthest_point_sample(_ptr(xyz), B, N, npoint, _ptr(start), _ptr(idx), _ptr(new_xyz),
+                                           _ptr(_err_word(dev)), _stream(dev))
+    _lib.check(rc, "pn2_farthest_point_sample")
+    _after_fault_op(dev, "farthest_point_sample")
+    return idx, new_xyz
+
+
+def farthest_point_sample(xyz, npoint, start=None):
+    return farthest_point_sample_with_xyz(xyz, npoint, start)[0]
+
+
+def square_distance(src, dst):
+    dev = _dev(src, dst)
+    lib = _lib.load()
+    src, dst = _f32c(src), _f32c(dst)
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = torch.empty((B, N, M), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_square_distance(_ptr(src), _ptr(dst), B, N, M, _ptr(out), _stream(dev))
+    _lib.check(rc, "pn2_square_distance")
+    return out
+
+
+# ---------------------------------------------------------------------------------- grouping
+def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped):
+    dev = _dev(xyz, new_xyz, points)
+    lib = _lib.load()
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    D = 0 if points is None else points.shape[2]
+    idx = torch.empty((B, S, nsample), dtype=torch.int64, device=dev)
+    grouped = torch.empty((B, S, nsample, 3 + D), dtype=torch.float32, device=dev) if want_grouped else None
+    with torch.cuda.device(dev):
+        rc = lib.pn2_ball_query_group(float(radius), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(points), B, N, S,
+                                      D, _ptr(idx), _ptr(grouped), _ptr(_err_word(dev)), _stream(dev))
+    _lib.check(rc, "pn2_ball_query_group")
+    _after_fault_op(dev, "query_ball_point")
+    return idx, grouped
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    idx, _ = _ball_query_group_raw(radius, nsample, _f32c(xyz), _f32c(new_xyz), None, False)
+    return idx
+
+
+class _BallQueryGroup(torch.autograd.Function):
+    """idx, grouped = f(xyz, new_xyz, points); d grouped / d points is a scatter-add.
+    xyz / new_xyz receive no gradient: in the network they derive from the input cloud only
+    (SURVEY.md 3.3)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, points, radius, nsample):
+        idx, grouped = _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, True)
+        ctx.save_for_backward(idx)
+        ctx.shape = (xyz.shape[0], xyz.shape[1], 0 if points is None else points.shape[2])
+        ctx.mark_non_differentiable(idx)
+        return idx, grouped
+
+    @staticmethod
+    def backward(ctx, _gidx, ggrouped):
+        (idx,) = ctx.saved_tensors
+        B, N, D = ctx.shape
+        if D == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None, None
+        return None, None, index_points_backward(ggrouped, idx, N, D, col0=3), None, None
+
+
+def ball_query_group(radius, nsample, xyz, new_xyz, points):
+    """Fused query_ball_point + grouping: (idx [B,S,K] int64, grouped [B,S,K,3+D])."""
+    xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
+    if points is not None:
+        points = points.to(torch.float32).contiguous()
+    return _BallQueryGroup.apply(xyz, new_xyz, points, radius, nsample)
+
+
+def index_points_backward(grad_out, idx, N, D, col0=0):
+    """grad_points[B,N,D] = scatter-add of grad_out[B,...,Cg][..., col0:col0+D] at idx."""
+    dev = _dev(grad_out, idx)
+    lib = _lib.load()
+    grad_out, idx = _f32c(grad_out), _i64c(idx)
+    B = idx.shape[0]
+    M = idx.numel() // max(B, 1)
+    Cg = grad_out.shape[-1]
+    gp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_index_points_backward(_ptr(grad_out), _ptr(idx), B, N, D, M, Cg, col0, _ptr(gp), _stream(dev))
+    _lib.check(rc, "pn2_index_points_backward")
+    return gp
+
+
+class _IndexPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        dev = _dev(points, idx)
+        lib = _lib.load()
+        B, N, C = points.shape
+        M = idx.numel() // max(B, 1)
+        out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_index_points(_ptr(points), _ptr(idx), B, N, C, M, _ptr(out), _ptr(_err_word(dev)),
+                                      _stream(dev))
+        _lib.check(rc, "pn2_index_points")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        N, C = ctx.shape
+        return index_points_backward(gout, idx, N, C), None
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,K] -> [B,S,(K,)C]  (models/pointnet2_utils.py:43-60)."""
+    dev = _dev(points, idx)
+    out = _IndexPoints.apply(points.to(torch.float32).contiguous(), _i64c(idx))
+    _after_fault_op(dev, "index_points")
+    return out
+
+
+class _GroupPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, points, idx):
+        dev = _dev(xyz, new_xyz, points, idx)
+        lib = _lib.load()
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        D = 0 if points is None else points.shape[2]
+        out = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_group_points(_ptr(xyz), _ptr(new_xyz), _ptr(points), _ptr(idx), B, N, S, K, D, _ptr(out),
+                                      _ptr(_err_word(dev)), _stream(dev))
+        _lib.check(rc, "pn2_group_points")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        N, D = ctx.shape
+        if D == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None
+        return None, None, index_points_backward(gout, idx, N, D, col0=3), None
+
+
+def group_points(xyz, new_xyz, points, idx):
+    """[xyz[idx]-new_xyz, points[idx]] for a given idx (models/pointnet2_utils.py:127-132)."""
+    dev = _dev(xyz, new_xyz, points, idx)
+    if points is not None:
+        points = points.to(torch.float32).contiguous()
+    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx))
+    _after_fault_op(dev, "group_points")
+    return out
+
+
+# ---------------------------------------------------------------------------------- interpolation
+def three_nn(xyz1, xyz2, want_dist=False):
+    """xyz1 [B,N,3] queries, xyz2 [B,S,3] -> idx3 [B,N,3] int64, weight3 [B,N,3] (, dist3)."""
+    dev = _dev(xyz1, xyz2)
+    lib = _lib.load()
+    xyz1, xyz2 = _f32c(xyz1), _f32c(xyz2)
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    idx3 = torch.empty((B, N, 3), dtype=torch.int64, device=dev)
+    w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    d3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if want_dist else None
+    with torch.cuda.device(dev):
+        rc = lib.pn2_three_nn(_ptr(xyz1), _ptr(xyz2), B, N, S, _ptr(idx3), _ptr(d3), _ptr(w3), _stream(dev))
+    _lib.check(rc, "pn2_three_nn")
+    return (idx3, w3, d3) if want_dist else (idx3, w3)
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points2, idx3, weight3):
+        dev = _dev(points2, idx3, weight3)
+        lib = _lib.load()
+        B, S, D = points2.shape
+        N = idx3.shape[1]
+        out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_three_interpolate(_ptr(points2), _ptr(idx3), _ptr(weight3), B, N, S, D, _ptr(out),
+                                           _stream(dev))
+        _lib.check(rc, "pn2_three_interpolate")
+        ctx.save_for_backward(idx3, weight3)
+        ctx.shape = (B, N, S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx3, weight3 = ctx.saved_tensors
+        B, N, S, D = ctx.shape
+        dev = gout.device
+        lib = _lib.load()
+        gout = _f32c(gout)
+        g2 = torch.zeros((B, S, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_three_interpolate_backward(_ptr(gout), _ptr(idx3), _ptr(weight3), B, N, S, D, _ptr(g2),
+                                                    _stream(dev))
+        _lib.check(rc, "pn2_three_interpolate_backward")
+        return g2, None, None
+
+
+def three_interpolate(points2, idx3, weight3):
+    """sum_k points2[idx3[...,k]] * weight3[...,k]  (models/pointnet2_utils.py:303)."""
+    return _ThreeInterpolate.apply(points2.to(torch.float32).contiguous(), _i64c(idx3), _f32c(weight3))

@@ -1,0 +1,317 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs and against the reference-generated golden fixtures.  Integer/index outputs must
+be identical; float outputs within the stated tolerance (log-probs 1e-3, BASELINE north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = ((1024, 0.1), (256, 0.2), (64, 0.4), (16, 0.8))
+KINDS = ("cube", "facade")
+
+
+@pytest.fixture(scope="module")
+def pn2():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    import khairil_tum_facade_semantic_segmentation_amd as pkg
+    from khairil_tum_facade_semantic_segmentation_amd import _lib, ops
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg, pointnet2_utils
+    _lib.load()                       # fails loudly if libpn2hip.so is missing
+    pkg.ops, pkg.U, pkg.M, pkg.torch = ops, pointnet2_utils, pointnet2_sem_seg, torch
+    return pkg
+
+
+def dev(pn2, a):
+    return pn2.torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------- index tensors, exact
+@pytest.mark.parametrize("kind", KINDS)
+def test_fps_ball_group_match_golden_and_oracle(pn2, orc, synth, golden, kind):
+    g = golden("geometry_" + kind)
+    blocks, _, _, _ = synth.draw_case(int(g["seed"]), 2, 4096, 9, kind)
+    cur = np.ascontiguousarray(blocks[:, :, :3])
+    feats = blocks
+    for lv, (npoint, radius) in enumerate(LEVELS, start=1):
+        fps, new_xyz = pn2.ops.farthest_point_sample_with_xyz(dev(pn2, cur), npoint, dev(pn2, g["start%d" % lv]))
+        assert np.array_equal(host(fps), g["fps%d" % lv].astype(np.int64)), "FPS level %d" % lv
+        want_xyz = orc.index_points(cur, host(fps))
+        assert np.array_equal(host(new_xyz), want_xyz)
+        idx, grouped = pn2.ops.ball_query_group(radius, 32, dev(pn2, cur), new_xyz, dev(pn2, feats))
+        assert np.array_equal(host(idx), g["ball%d" % lv].astype(np.int64)), "ball query level %d" % lv
+        assert np.array_equal(host(grouped), orc.group_points(cur, want_xyz, feats, host(idx))), "group level %d" % lv
+        if lv == 1:
+            assert np.array_equal(host(grouped)[:, ::41], g["group1_rows"])
+        only_idx = pn2.U.query_ball_point(radius, 32, dev(pn2, cur), new_xyz)
+        assert np.array_equal(host(only_idx), host(idx))
+        cur = want_xyz
+        feats = np.random.RandomState(lv).normal(size=(2, npoint, 5 + lv)).astype(np.float32)
+    pn2.ops.check_errors()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_square_distance_bit_exact(pn2, orc, synth, golden, kind):
+    g = golden("geometry_" + kind)
+    blocks, _, _, _ = synth.draw_case(int(g["seed"]), 2, 4096, 9, kind)
+    xyz = np.ascontiguousarray(blocks[:, :, :3])
+    l1 = orc.index_points(xyz, g["fps1"].astype(np.int64))
+    d = host(pn2.U.square_distance(dev(pn2, l1[:, :64]), dev(pn2, xyz[:, :512])))
+    assert np.array_equal(d.view(np.uint32), g["sqdist_1024x4096_tile"].view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_three_nn_interpolate(pn2, orc, synth, golden, kind):
+    g = golden("geometry_" + kind)
+    blocks, _, _, _ = synth.draw_case(int(g["seed"]), 2, 4096, 9, kind)
+    xyzs = [np.ascontiguousarray(blocks[:, :, :3])]
+    for lv in range(1, 5):
+        xyzs.append(orc.index_points(xyzs[-1], g["fps%d" % lv].astype(np.int64)))
+    frs = np.random.RandomState(int(g["nn_feat_seed"]))
+    for lv in (3, 2, 1, 0):
+        idx3, w3, d3 = pn2.ops.three_nn(dev(pn2, xyzs[lv]), dev(pn2, xyzs[lv + 1]), want_dist=True)
+        oi, od, ow = orc.three_nn(xyzs[lv], xyzs[lv + 1])
+        assert np.array_equal(host(idx3), oi)                 # same tie rule as the oracle: identical everywhere
+        assert np.array_equal(host(d3), od)
+        np.testing.assert_allclose(host(w3), ow, rtol=2e-6, atol=1e-7)
+        ok = ~g["nn%d_tie" % lv]                              # vs the reference: wherever its pick is pinned
+        assert np.array_equal(host(idx3)[ok], g["nn%d_idx" % lv].astype(np.int64)[ok])
+        p2 = frs.normal(size=(2, xyzs[lv + 1].shape[1], 16)).astype(np.float32)
+        interp = host(pn2.ops.three_interpolate(dev(pn2, p2), idx3, w3))
+        np.testing.assert_allclose(interp[ok], g["nn%d_interp" % lv][ok], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("B,N,S,K,D", [(1, 1, 1, 1, 0), (2, 63, 5, 4, 1), (3, 65, 33, 16, 3), (2, 1000, 100, 32, 6),
+                                       (1, 4097, 70, 64, 2), (2, 9000, 257, 32, 9), (1, 300, 300, 7, 67)])
+def test_ball_query_group_ragged_shapes(pn2, orc, B, N, S, K, D):
+    rs = np.random.RandomState(B * 1000 + N)
+    xyz = rs.uniform(-0.5, 0.5, size=(B, N, 3)).astype(np.float32)
+    xyz[:, N // 2] = xyz[:, 0]                               # a duplicated point takes its own slot
+    pick = np.stack([rs.choice(N, S, replace=S > N) for _ in range(B)])
+    new_xyz = orc.index_points(xyz, pick)
+    pts = rs.normal(size=(B, N, D)).astype(np.float32) if D else None
+    radius = 0.35
+    idx, grouped = pn2.ops.ball_query_group(radius, K, dev(pn2, xyz), dev(pn2, new_xyz),
+                                            None if pts is None else dev(pn2, pts))
+    want = orc.query_ball_point(radius, K, xyz, new_xyz)
+    assert np.array_equal(host(idx), want)
+    assert np.array_equal(host(grouped), orc.group_points(xyz, new_xyz, pts, want))
+    again = pn2.ops.group_points(dev(pn2, xyz), dev(pn2, new_xyz), None if pts is None else dev(pn2, pts), idx)
+    assert np.array_equal(host(again), host(grouped))
+    pn2.ops.check_errors()
+
+
+@pytest.mark.parametrize("B,N,npoint", [(1, 1, 1), (2, 50, 50), (3, 64, 16), (2, 100, 7), (1, 129, 129), (2, 777, 300),
+                                        (1, 2048, 64), (2, 5000, 40), (1, 9001, 33), (1, 20000, 20)])
+def test_fps_ragged_shapes(pn2, orc, B, N, npoint):
+    rs = np.random.RandomState(N)
+    xyz = rs.normal(size=(B, N, 3)).astype(np.float32)
+    xyz[:, N - 1] = xyz[:, 0]                                # exact duplicate -> argmax tie -> lowest index
+    start = rs.randint(0, N, size=(B,))
+    idx, new_xyz = pn2.ops.farthest_point_sample_with_xyz(dev(pn2, xyz), npoint, dev(pn2, start))
+    want = orc.farthest_point_sample(xyz, npoint, start)
+    assert np.array_equal(host(idx), want)
+    assert np.array_equal(host(new_xyz), orc.index_points(xyz, want))
+
+
+def test_fps_all_points_identical(pn2, orc):
+    xyz = np.ones((2, 200, 3), np.float32)
+    start = np.array([5, 199])
+    got = host(pn2.ops.farthest_point_sample(dev(pn2, xyz), 8, dev(pn2, start)))
+    assert np.array_equal(got, orc.farthest_point_sample(xyz, 8, start))    # all distances 0 -> index 0 forever
+
+
+@pytest.mark.parametrize("B,N,S", [(1, 5, 3), (2, 100, 3), (2, 1000, 37), (1, 70, 2500), (1, 4096, 4100)])
+def test_three_nn_ragged_shapes(pn2, orc, B, N, S):
+    rs = np.random.RandomState(N + S)
+    xyz1 = rs.normal(size=(B, N, 3)).astype(np.float32)
+    xyz2 = rs.normal(size=(B, S, 3)).astype(np.float32)
+    xyz2[:, S - 1] = xyz2[:, 0]                              # exact tie -> lowest index first
+    idx3, w3, d3 = pn2.ops.three_nn(dev(pn2, xyz1), dev(pn2, xyz2), want_dist=True)
+    oi, od, ow = orc.three_nn(xyz1, xyz2)
+    assert np.array_equal(host(idx3), oi)
+    assert np.array_equal(host(d3), od)
+    np.testing.assert_allclose(host(w3), ow, rtol=2e-6, atol=1e-7)
+    for D in (1, 5, 64):
+        p2 = rs.normal(size=(B, S, D)).astype(np.float32)
+        got = host(pn2.ops.three_interpolate(dev(pn2, p2), idx3, w3))
+        np.testing.assert_allclose(got, orc.three_interpolate(p2, oi, ow), rtol=1e-6, atol=1e-6)
+
+
+def test_empty_ball_reports_index_error(pn2):
+    xyz = np.zeros((1, 100, 3), np.float32)
+    far = np.full((1, 3, 3), 7.0, np.float32)
+    pn2.ops.set_error_mode("eager")
+    try:
+        with pytest.raises(IndexError):
+            pn2.U.query_ball_point(0.1, 8, dev(pn2, xyz), dev(pn2, far))
+    finally:
+        pn2.ops.set_error_mode("lazy")
+    idx = pn2.U.query_ball_point(0.1, 8, dev(pn2, xyz), dev(pn2, far))
+    assert (host(idx) == 100).all()
+    with pytest.raises(IndexError):
+        pn2.ops.check_errors()
+    pn2.ops.check_errors()                                    # counter was reset
+    with pytest.raises(IndexError):
+        pn2.ops.set_error_mode("eager")
+        try:
+            pn2.U.index_points(dev(pn2, xyz), dev(pn2, np.array([[0, 100]])))
+        finally:
+            pn2.ops.set_error_mode("lazy")
+
+
+def test_cpu_tensors_are_refused(pn2):
+    t = pn2.torch.zeros(1, 8, 3)
+    with pytest.raises(RuntimeError):
+        pn2.U.farthest_point_sample(t, 2)
+
+
+# ------------------------------------------------------------------------- backward kernels
+def test_gather_and_interpolate_backward(pn2, orc):
+    torch = pn2.torch
+    rs = np.random.RandomState(5)
+    B, N, S, K, D = 2, 500, 60, 16, 24
+    xyz = rs.uniform(-0.5, 0.5, size=(B, N, 3)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    pts = rs.normal(size=(B, N, D)).astype(np.float32)
+    tp = dev(pn2, pts).requires_grad_(True)
+    idx, grouped = pn2.ops.ball_query_group(0.3, K, dev(pn2, xyz), dev(pn2, new_xyz), tp)
+    go = rs.normal(size=grouped.shape).astype(np.float32)
+    grouped.backward(dev(pn2, go))
+    want = orc.index_points_backward(go.reshape(B, S * K, 3 + D), host(idx), N, D, col0=3)
+    np.testing.assert_allclose(host(tp.grad), want, rtol=1e-5, atol=1e-5)    # atomics: order differs
+
+    tp2 = dev(pn2, pts).requires_grad_(True)
+    sel = dev(pn2, rs.randint(0, N, size=(B, 77)))
+    out = pn2.U.index_points(tp2, sel)
+    go2 = rs.normal(size=out.shape).astype(np.float32)
+    out.backward(dev(pn2, go2))
+    np.testing.assert_allclose(host(tp2.grad), orc.index_points_backward(go2, host(sel), N, D), rtol=1e-5, atol=1e-5)
+
+    p2 = rs.normal(size=(B, S, D)).astype(np.float32)
+    tp3 = dev(pn2, p2).requires_grad_(True)
+    idx3, w3 = pn2.ops.three_nn(dev(pn2, xyz), dev(pn2, new_xyz))
+    o = pn2.ops.three_interpolate(tp3, idx3, w3)
+    go3 = rs.normal(size=o.shape).astype(np.float32)
+    o.backward(dev(pn2, go3))
+    want3 = orc.three_interpolate_backward(go3, host(idx3), host(w3), S)
+    np.testing.assert_allclose(host(tp3.grad), want3, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------- whole network
+def _load(pn2, synth, orc, model, K, C):
+    filled = synth.fill_state_dict(orc.state_shapes(K, C - 6))
+    model.load_state_dict({k: pn2.torch.from_numpy(v) for k, v in filled.items()})
+    return filled
+
+
+EVAL_CASES = (("cube", 9, 18), ("facade", 9, 18), ("cube", 6, 18), ("cube", 9, 8), ("facade", 6, 8))
+
+
+@pytest.mark.parametrize("kind,C,K", EVAL_CASES)
+def test_network_eval_logprobs_within_1e3(pn2, orc, synth, golden, kind, C, K):
+    torch = pn2.torch
+    g = golden("model_eval_%s_c%d_k%d" % (kind, C, K))
+    blocks, _, starts, _ = synth.draw_case(int(g["seed"]), 1, 4096, C, kind, K)
+    model = pn2.M.get_model(K, C - 6)
+    _load(pn2, synth, orc, model, K, C)
+    model = model.cuda().eval()
+    taps = {}
+    if "tap_sa1" in g:
+        for name in ("sa1", "sa2", "sa3", "sa4", "fp4", "fp3", "fp2", "fp1"):
+            mod = getattr(model, name)
+            orig = mod.forward_cl
+
+            def wrapped(*a, _orig=orig, _name=name, **kw):
+                out = _orig(*a, **kw)
+                taps[_name] = (out[1] if isinstance(out, tuple) else out).detach()
+                return out
+            mod.forward_cl = wrapped
+    with torch.no_grad(), pn2.U.fps_starts(starts):
+        logp, l4 = model(dev(pn2, blocks).permute(0, 2, 1))
+    pn2.ops.check_errors()
+    ok = ~g["tie_points"]
+    err = np.abs(host(logp) - g["logp"])[ok].max()
+    assert err <= 1e-3, err                                   # north_star: within 1e-3 fp32
+    assert np.abs(host(l4) - g["l4_points"]).max() <= 1e-3
+    for name, t in taps.items():
+        got = host(t.permute(0, 2, 1))
+        ref = g["tap_" + name]
+        if name == "fp1":
+            got = got[:, :, ::8]
+            assert np.abs(got - ref)[:, :, ok[0, ::8]].max() <= 1e-3, name
+        else:
+            assert np.abs(got - ref).max() <= 1e-3, name
+
+
+@pytest.mark.parametrize("kind,C,K", (("cube", 9, 18), ("facade", 6, 8)))
+def test_network_train_step_matches_reference(pn2, orc, synth, golden, kind, C, K):
+    torch = pn2.torch
+    g = golden("model_train_%s_c%d_k%d" % (kind, C, K))
+    blocks, labels, starts, cw = synth.draw_case(int(g["seed"]), 2, 4096, C, kind, K)
+    model = pn2.M.get_model(K, C - 6)
+    _load(pn2, synth, orc, model, K, C)
+    model = model.cuda().train()
+    model.drop1.p = 0.0
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    opt.zero_grad()
+    with pn2.U.fps_starts(starts):
+        pred, tf = model(dev(pn2, blocks).permute(0, 2, 1))
+    loss = pn2.M.get_loss()(pred.contiguous().view(-1, K), dev(pn2, labels).view(-1), tf, dev(pn2, cw))
+    loss.backward()
+    pn2.ops.check_errors()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3
+    params = dict(model.named_parameters())
+    for key in g:
+        if key.startswith("grad:"):
+            ref = g[key]
+            got = host(params[key[5:]].grad)
+            assert np.abs(got - ref).max() <= 1e-4 + 2e-3 * np.abs(ref).max(), key
+    opt.step()
+    for key in g:
+        if key.startswith("adam:"):
+            firm = np.abs(g["grad:" + key[5:]]) > 1e-3          # lr*sign(g) is only defined for firm gradients
+            diff = np.abs(host(params[key[5:]]) - g[key])
+            assert diff[firm].max(initial=0.0) <= 1e-4, key
+    sd = model.state_dict()
+    for key in g:
+        if key.startswith("buf:"):
+            assert np.abs(host(sd[key[4:]]) - g[key]).max() <= 1e-3, key
+
+
+# ------------------------------------------------------------------------- full size, properties
+def test_full_size_properties_b16(pn2, orc, synth):
+    """BASELINE config 2 shape (16 x 4096 x 9): size-independent properties on every block plus
+    an exact oracle comparison on a sample of blocks."""
+    blocks, _, starts, _ = synth.draw_case(synth.BENCH_SEED, 16, 4096, 9, "facade")
+    xyz = np.ascontiguousarray(blocks[:, :, :3])
+    fps, new_xyz = pn2.ops.farthest_point_sample_with_xyz(dev(pn2, xyz), 1024, dev(pn2, starts[0]))
+    idx, grouped = pn2.ops.ball_query_group(0.1, 32, dev(pn2, xyz), new_xyz, dev(pn2, blocks))
+    fps, idx, grouped = host(fps), host(idx), host(grouped)
+    assert np.array_equal(fps[:, 0], starts[0])
+    assert fps.min() >= 0 and fps.max() < 4096
+    assert all(len(np.unique(r)) == 1024 for r in fps)        # distinct points are never re-picked
+    assert idx.min() >= 0 and idx.max() < 4096
+    d = np.diff(idx, axis=-1)
+    # strictly ascending until the padding starts, then constant == first hit
+    pad = idx == idx[:, :, :1]
+    pad[:, :, 0] = False
+    firstpad = np.where(pad.any(-1), pad.argmax(-1), 32)
+    k = np.arange(31)[None, None, :]
+    assert ((d > 0) | (k + 1 >= firstpad[:, :, None])).all()
+    assert (np.linalg.norm(grouped[..., :3].astype(np.float64), axis=-1) <= 0.1 + 1e-4).all()
+    # the centroid is its own neighbour (distance 0): relative xyz has an exact zero row
+    assert (np.abs(grouped[..., :3]).sum(-1) == 0).any(-1).all()
+    for b in (0, 7, 15):
+        want_fps = orc.farthest_point_sample(xyz[b:b + 1], 1024, starts[0][b:b + 1])
+        assert np.array_equal(fps[b:b + 1], want_fps)
+        cxyz = orc.index_points(xyz[b:b + 1], want_fps)
+        want_idx = orc.query_ball_point(0.1, 32, xyz[b:b + 1], cxyz)
+        assert np.array_equal(idx[b:b + 1], want_idx)
+        assert np.array_equal(grouped[b:b + 1], orc.group_points(xyz[b:b + 1], cxyz, blocks[b:b + 1], want_idx))
