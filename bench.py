@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- points/sec fwd+bwd of pointnet2_sem_seg on 4096-point blocks (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (forward, nll_loss, backward, gradient all-reduce when N>1,
+Adam) on a per-GPU batch of 16 synthetic 4096x9 blocks already resident in HBM (BASELINE
+configs[1]).  Rank 0 prints ONE JSON line; `roofline` prices the query_ball_point+group kernel
+of SA1 (the kernel the north_star names) against the HBM roof; `cpu_baseline` is the CPU oracle
+timed on the host cores on a bounded sample (N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
+BLOCK_POINTS = 4096
+PER_GPU_BATCH = 16
+CHANNELS = 9
+NUM_CLASSES = 18
+
+
+def ball_group_algorithmic_bytes(B, N, S, K, D):
+    """read xyz + new_xyz + feats once, write int64 idx + fp32 grouped once."""
+    return B * (N * 3 * 4 + S * 3 * 4 + N * D * 4 + S * K * 8 + S * K * (3 + D) * 4)
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU oracle (oracle/: C index ops + torch CPU network), fwd+bwd+Adam on the same
+    synthetic blocks.  Bounded: at most 3 steps of B=16, stops once `seconds_budget` is spent."""
+    from khairil_tum_facade_semantic_segmentation_amd import synth
+    from oracle import pn2_oracle as orc
+    orc.build()
+    threads = torch.get_num_threads()
+    orc.set_num_threads(threads)
+    filled = synth.fill_state_dict(orc.state_shapes(NUM_CLASSES, CHANNELS - 6))
+    net = orc.OracleNet(filled)
+    opt = orc.make_adam(net.parameters())
+    blocks, labels, starts, _ = synth.draw_case(synth.BENCH_SEED, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, "cube",
+                                                NUM_CLASSES)
+    cf = np.ascontiguousarray(blocks.transpose(0, 2, 1))
+    net.train_step(cf[:2], labels[:2], [s[:2] for s in starts], opt)          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 and (n == 0 or time.perf_counter() - t0 < seconds_budget):
+        net.train_step(cf, labels, starts, opt)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * PER_GPU_BATCH * BLOCK_POINTS / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": "%d fwd+bwd+Adam step(s) of %dx%dx%d cube blocks, %.1f s, oracle (C index ops + torch CPU)"
+                      % (n, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--kind", default="cube", choices=("cube", "facade"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from khairil_tum_facade_semantic_segmentation_amd import _lib, ops, synth
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+    from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
+    from oracle import pn2_oracle as orc
+    _lib.load()
+
+    # synthetic blocks of this rank (weak scaling: 16 blocks per GPU), resident in HBM
+    blocks, labels, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind,
+                                           NUM_CLASSES)
+    x = torch.from_numpy(np.ascontiguousarray(blocks.transpose(0, 2, 1))).to(dev)     # [B,C,N]
+    y = torch.from_numpy(labels).to(dev)
+    filled = synth.fill_state_dict(orc.state_shapes(NUM_CLASSES, CHANNELS - 6))
+    model = M.get_model(NUM_CLASSES, CHANNELS - 6)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model = model.to(dev)
+    trainer = SemSegTrainer(model, class_weight=torch.ones(NUM_CLASSES, device=dev))
+    trainer.broadcast_parameters()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.check_errors()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "training step produced a non-finite loss"
+
+    # roofline of the north_star kernel: SA1 query_ball_point+group at B=16, N=4096, S=1024, K=32, D=9,
+    # HIP events on the launch stream, same resident inputs as the timed steps.
+    pts = x.permute(0, 2, 1).contiguous()
+    xyz = pts[:, :, :3].contiguous()
+    _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, 1024)
+    reps = 50
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for _ in range(5):
+        ops._ball_query_group_raw(0.1, 32, xyz, new_xyz, pts, True)
+    torch.cuda.synchronize(dev)
+    for a, b in ev:
+        a.record()
+        ops._ball_query_group_raw(0.1, 32, xyz, new_xyz, pts, True)
+        b.record()
+    torch.cuda.synchronize(dev)
+    k_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    algo = ball_group_algorithmic_bytes(PER_GPU_BATCH, BLOCK_POINTS, 1024, 32, CHANNELS)
+    achieved = algo / (k_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_points = world * PER_GPU_BATCH * BLOCK_POINTS * args.steps
+        out = {
+            "metric": "points/sec fwd+bwd, 4096-pt blocks, pointnet2_sem_seg",
+            "value": total_points / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "pointnet2_sem_seg fwd+bwd+Adam, batch=16x4096x9 synthetic %s blocks per GPU, "
+                                   "npoint=[1024,256,64,16] nsample=32, 18 classes (BASELINE configs[1])" % args.kind,
+                       "global_batch": world * PER_GPU_BATCH, "points_per_block": BLOCK_POINTS,
+                       "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "ball_query_group_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": algo, "kernel_ms": k_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,10 @@
 
 namespace pn2 {
 
+// Developer tuning knob: PN2_TUNE_<NAME>=<int> in the environment overrides a launch heuristic
+// (read on every call: benchmarks only, never set in production).
+int tune_get(const char *name, int dflt);
+
 // |p|^2 exactly as torch.sum(p ** 2, -1) evaluates it: ((x*x + y*y) + z*z), every op rounded
 // (reference models/pointnet2_utils.py:38-39; rule SURVEY.md 8a-2).
 __device__ __forceinline__ float norm3(float x, float y, float z)

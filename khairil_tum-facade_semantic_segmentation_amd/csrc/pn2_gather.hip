@@ -2,6 +2,10 @@
 // square_distance, on gfx950.  Reference: models/pointnet2_utils.py:43-60 (advanced indexing),
 // :127-132 (grouping), :19-40 (square_distance).  All HBM-bound streaming kernels: lanes run
 // along the contiguous channel axis so every wave-instruction touches whole rows.
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "pn2_common.h"
 
 namespace {
@@ -88,6 +92,15 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float *__res
 }
 
 }  // namespace
+
+int pn2::tune_get(const char *name, int dflt)
+{
+    char key[64];
+    snprintf(key, sizeof(key), "PN2_TUNE_%s", name);
+    for (char *c = key; *c; ++c) *c = (char)toupper((unsigned char)*c);
+    const char *v = getenv(key);
+    return v ? atoi(v) : dflt;
+}
 
 PN2_EXPORT int pn2_abi_version(void) { return PN2_ABI_VERSION; }
 
