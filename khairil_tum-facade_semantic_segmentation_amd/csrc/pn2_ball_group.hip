@@ -2,33 +2,78 @@
 //
 // Reference (models/pointnet2_utils.py:87-107, 127-132) materialises a [B,S,N] distance
 // matrix, masks it, fully sorts a [B,S,N] int64 tensor and gathers three times.  Here a
-// workgroup stages one block's xyz (+|p|^2) in LDS once, every wave owns CPW centroids and
-// scans the points 64 at a time in ascending index order (lane = point, centroid in SGPRs),
-// appending hits with ballot + mbcnt so the "nsample lowest indices" rule holds by
-// construction and a centroid stops as soon as it has nsample hits.  The same wave then
-// writes idx (int64) and the grouped rows [xyz-centroid, feats] with 256-B coalesced stores.
-// Bound: HBM (the grouped tensor write); algorithmic bytes in DESIGN.md.
+// workgroup stages one block's xyz (+|p|^2) in LDS once; every wave owns CPW centroids and
+// scans the points 64 at a time in ascending index order (lane = point), two centroids per
+// packed-fp32 instruction, appending hits with ballot + mbcnt so the "nsample lowest indices"
+// rule holds by construction and a centroid stops as soon as it has nsample hits.  The same
+// wave then writes idx (int64) and the grouped rows [xyz-centroid, feats] with coalesced
+// stores.  Measured (rocprofv3 PMC): the scan is VALU-issue bound (one wave-instruction per
+// SIMD per 4 clocks), so the kernel is written to minimise issued instructions; the roof it is
+// priced against is HBM (the grouped-tensor write).  Algorithmic bytes: DESIGN.md.
 #include <math.h>
 
 #include "pn2_common.h"
 
 namespace {
 
-constexpr int BQ_TILE = 4096;                 // points staged in LDS per pass (64 KiB as float4)
-constexpr int BQ_UNROLL = 8;                  // independent gathers in flight per lane in the group phase
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// THREADS per workgroup, CPW centroids per wave.
+constexpr int BQ_TILE = 4096;                 // points staged in LDS per pass (64 KiB as float4)
+constexpr int BQ_UNROLL = 8;                  // independent gathers in flight per lane (generic group phase)
+
+// Packed fp32 (two centroids per instruction).  Each half is an IEEE op identical to the scalar
+// one: mul / fma / add round exactly like v_mul_f32 / v_fma_f32 / v_add_f32.
+// p broadcast from the LOW half of `p`: r = (p.lo*c.lo, p.lo*c.hi)
+__device__ __forceinline__ v2f pk_mul_plo(v2f p, v2f c)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(p), "v"(c));
+    return r;
+}
+// r = (p.hi*c.lo + a.lo, p.hi*c.hi + a.hi)
+__device__ __forceinline__ v2f pk_fma_phi(v2f p, v2f c, v2f a)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(p), "v"(c), "v"(a));
+    return r;
+}
+// r = (p.lo*c.lo + a.lo, p.lo*c.hi + a.hi)
+__device__ __forceinline__ v2f pk_fma_plo(v2f p, v2f c, v2f a)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(p), "v"(c), "v"(a));
+    return r;
+}
+// r = (x.lo*y.lo + a.lo, x.hi*y.hi + a.hi)
+__device__ __forceinline__ v2f pk_fma(v2f x, v2f y, v2f a)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(a));
+    return r;
+}
+// r = (t.lo + p.hi, t.hi + p.hi)
+__device__ __forceinline__ v2f pk_add_phi(v2f t, v2f p)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(t), "v"(p));
+    return r;
+}
+
+// THREADS per workgroup, CPW (even) centroids per wave.
 template <int THREADS, int CPW>
 __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
     int B, int N, int S, int K, int D, float r2, int tiles_per_block, unsigned cg_magic,
-    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count)
+    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
 {
+    static_assert(CPW % 2 == 0, "centroids are processed in packed pairs");
     constexpr int WAVES = THREADS / PN2_WAVE;
+    constexpr int PAIRS = CPW / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *pts = reinterpret_cast<float4 *>(smem);                                   // [min(N,BQ_TILE) up to x64]
+    float4 *pts = reinterpret_cast<float4 *>(smem);                                   // [tile_pts]
     const int tile_pts = min(BQ_TILE, (N + PN2_WAVE - 1) & ~(PN2_WAVE - 1));
-    int *lists = reinterpret_cast<int *>(smem + (size_t)tile_pts * sizeof(float4));   // [WAVES][CPW][K]
+    const int lcap = K + PN2_WAVE;                       // a chunk may overshoot K by < 64 entries
+    int *lists = reinterpret_cast<int *>(smem + (size_t)tile_pts * sizeof(float4));   // [WAVES][CPW][lcap]
 
     const unsigned logical = pn2::xcd_remap(blockIdx.x, gridDim.x);
     const int b = (int)(logical / (unsigned)tiles_per_block);
@@ -37,58 +82,111 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     const int lane = tid & (PN2_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / PN2_WAVE);
     const int s0 = (tile * WAVES + wave) * CPW;
-    int *mylist = lists + (size_t)wave * CPW * K;
+    int *mylist = lists + (size_t)wave * CPW * lcap;
 
     const float *bx = xyz + (size_t)b * N * 3;
     const float *bc = new_xyz + (size_t)b * S * 3;
 
-    float cx[CPW], cy[CPW], cz[CPW], cn[CPW];
-    int cnt[CPW];
+    v2f cx2[PAIRS], cy2[PAIRS], cz2[PAIRS], cn2[PAIRS];
+    int cnt[CPW];                                         // hits so far; >= K means "done"
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int s = min(s0 + c, S - 1);
-        cx[c] = bc[s * 3 + 0];
-        cy[c] = bc[s * 3 + 1];
-        cz[c] = bc[s * 3 + 2];
-        cn[c] = pn2::norm3(cx[c], cy[c], cz[c]);
-        cnt[c] = (s0 + c < S) ? 0 : K;        // centroids past S are "done"
+        const float x = bc[s * 3 + 0], y = bc[s * 3 + 1], z = bc[s * 3 + 2];
+        cx2[c / 2][c & 1] = x;
+        cy2[c / 2][c & 1] = y;
+        cz2[c / 2][c & 1] = z;
+        cn2[c / 2][c & 1] = pn2::norm3(x, y, z);
+        cnt[c] = (s0 + c < S) ? 0 : K;                    // centroids past S never collect
+    }
+    v2f minus2 = {-2.0f, -2.0f};
+    // Pin the per-centroid constants in VGPR pairs: left alone, hipcc keeps these wave-uniform
+    // values in SGPRs and re-materialises a VGPR copy (v_mov_b64) in front of every packed op.
+    asm volatile("" : "+v"(minus2));
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        asm volatile("" : "+v"(cx2[q]));
+        asm volatile("" : "+v"(cy2[q]));
+        asm volatile("" : "+v"(cz2[q]));
+        asm volatile("" : "+v"(cn2[q]));
     }
 
     for (int n0 = 0; n0 < N; n0 += BQ_TILE) {
         if (n0) __syncthreads();
         const int npad = min(tile_pts, (N - n0 + PN2_WAVE - 1) & ~(PN2_WAVE - 1));
-        for (int j = tid; j < npad; j += THREADS) {
-            const int g = n0 + j;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, INFINITY);   // padding: d = +inf, never a hit
-            if (g < N) {
-                v.x = bx[g * 3 + 0];
-                v.y = bx[g * 3 + 1];
-                v.z = bx[g * 3 + 2];
-                v.w = pn2::norm3(v.x, v.y, v.z);
+        // Stage xyz (+|p|^2) of this tile: all of a thread's global loads are issued before the
+        // first is consumed (one round of memory latency per tile, not one per point).
+        {
+            constexpr int PT = BQ_TILE / THREADS;                 // points per thread per tile
+            float sx[PT], sy[PT], sz[PT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int j = tid + i * THREADS;
+                const int g = n0 + j;
+                const bool in = j < npad && g < N;
+                const int gg = in ? g : 0;
+                sx[i] = bx[gg * 3 + 0];
+                sy[i] = bx[gg * 3 + 1];
+                sz[i] = bx[gg * 3 + 2];
             }
-            pts[j] = v;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int j = tid + i * THREADS;
+                const int g = n0 + j;
+                if (j < npad) {
+                    const bool in = g < N;
+                    // padding: d = +inf, never a hit
+                    pts[j] = in ? make_float4(sx[i], sy[i], sz[i], pn2::norm3(sx[i], sy[i], sz[i]))
+                                : make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+                }
+            }
         }
         __syncthreads();
-        const int nchunks = npad / PN2_WAVE;
+        const int nchunks = (dbg & 1) ? 0 : npad / PN2_WAVE;
+        float4 pnext = pts[lane];
         for (int ch = 0; ch < nchunks; ++ch) {
-            bool all_done = true;
+            const float4 p = pnext;
+            if (ch + 1 < nchunks) pnext = pts[(ch + 1) * PN2_WAVE + lane];      // prefetch: LDS latency off the chain
+            const v2f pxy = {p.x, p.y};
+            const v2f pzw = {p.z, p.w};
+            unsigned long long m[CPW];
+            bool hit[CPW];
+            unsigned long long any = 0;
+            // src = new_xyz (centroid), dst = xyz (point): pointnet2_utils.py:101, 37-39.
+            // Stage-wise over the PAIRS independent chains so dependent packed ops never issue
+            // back to back.
+            v2f t[PAIRS];
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) all_done = all_done && (cnt[c] >= K);
-            if (all_done) break;
-            const float4 p = pts[ch * PN2_WAVE + lane];
+            for (int q = 0; q < PAIRS; ++q) t[q] = pk_mul_plo(pxy, cx2[q]);          // a0*b0
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-                if (cnt[c] < K) {
-                    // src = new_xyz (centroid), dst = xyz (point): pointnet2_utils.py:101
-                    const float d = pn2::pair_sqdist(cx[c], cy[c], cz[c], cn[c], p.x, p.y, p.z, p.w);
-                    const bool hit = !(d > r2);                                  // :102
-                    const unsigned long long m = __ballot(hit);
-                    if (m) {
-                        const int pos = cnt[c] + pn2::mbcnt(m);
-                        if (hit && pos < K) mylist[c * K + pos] = n0 + ch * PN2_WAVE + lane;
-                        cnt[c] += __builtin_popcountll(m);
+            for (int q = 0; q < PAIRS; ++q) t[q] = pk_fma_phi(pxy, cy2[q], t[q]);    // fma(a1,b1,.)
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) t[q] = pk_fma_plo(pzw, cz2[q], t[q]);    // fma(a2,b2,.) = dot
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) t[q] = pk_fma(t[q], minus2, cn2[q]);     // (-2*dot) + |centroid|^2, one rounding
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) t[q] = pk_add_phi(t[q], pzw);            // + |point|^2
+#pragma unroll
+            for (int q = 0; q < PAIRS; ++q) {
+                hit[2 * q] = !(t[q].x > r2);                     // :102  (hit = not masked out)
+                hit[2 * q + 1] = !(t[q].y > r2);
+                m[2 * q] = __ballot(hit[2 * q]);
+                m[2 * q + 1] = __ballot(hit[2 * q + 1]);
+                any |= m[2 * q] | m[2 * q + 1];
+            }
+            if (any && !(dbg & 2)) {
+                const int pidx = n0 + ch * PN2_WAVE + lane;
+                bool still = false;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) {
+                    if (m[c] && cnt[c] < K) {                    // a full centroid ignores later hits
+                        const int pos = cnt[c] + pn2::mbcnt(m[c]);
+                        if (hit[c]) mylist[c * lcap + pos] = pidx;
+                        cnt[c] += __builtin_popcountll(m[c]);
                     }
+                    still = still || (cnt[c] < K);
                 }
+                if (!still) break;                               // every centroid of this wave is full
             }
         }
     }
@@ -100,8 +198,9 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     for (int c = 0; c < CPW; ++c) {
         const int s = s0 + c;
         if (s >= S) break;
+        int *lst = mylist + c * lcap;
+        if (dbg && cnt[c] == 0) { cnt[c] = 1; lst[0] = 0; }
         const int n = min(cnt[c], K);
-        int *lst = mylist + c * K;
         int64_t *orow = idx + ((size_t)b * S + s) * K;
         if (n == 0) {                                       // reference: IndexError at :59
             if (lane == 0 && err_count) atomicAdd(err_count, 1);
@@ -118,16 +217,78 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     if (!grouped) return;
 
     // ---- grouped rows: [xyz[j]-centroid (3), points[j] (D)] for the wave's CPW centroids ----
-    // Elements of one centroid's [K, 3+D] block are walked 64 at a time (256-B coalesced
-    // stores); BQ_UNROLL independent gathers are issued before the first one is consumed.
     const float *bp = points ? points + (size_t)b * N * D : nullptr;
+    if (Cg >= 32) {
+        // Wide rows: one row per step, lanes along the channel axis (row base is wave-uniform).
+#pragma unroll 1
+        for (int c = 0; c < CPW; ++c) {
+            const int s = s0 + c;
+            if (s >= S) break;
+            const int *lst = mylist + c * lcap;
+            float *g = grouped + ((size_t)b * S + s) * row_elems;
+            const float ctr[3] = {cx2[c / 2][c & 1], cy2[c / 2][c & 1], cz2[c / 2][c & 1]};
+            // xyz part of all K rows: element e = k*3 + col
+            for (int e = lane; e < K * 3; e += PN2_WAVE) {
+                const int k = e / 3, col = e - k * 3;
+                const int j = lst[k];
+                const float cc = col == 0 ? ctr[0] : (col == 1 ? ctr[1] : ctr[2]);
+                g[k * Cg + col] = j >= 0 ? bx[(size_t)j * 3 + col] - cc : 0.0f;   // :128
+            }
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) {
+                const int j = __builtin_amdgcn_readfirstlane(lst[k]);
+                const float *src = bp + (size_t)max(j, 0) * D;
+                float *dst = g + (size_t)k * Cg + 3;
+                for (int col = lane; col < D; col += PN2_WAVE)
+                    dst[col] = j >= 0 ? src[col] : 0.0f;                        // :131-132
+            }
+        }
+        return;
+    }
+    if ((Cg & 3) == 0 && ((reinterpret_cast<uintptr_t>(grouped) & 15) == 0)) {
+        // Narrow rows whose width is a multiple of 4 floats (SA1: 3+9 = 12): one float4 of the
+        // output per lane and step; quad 0 of a row is [xyz - centroid, feat0], quad p > 0 is
+        // feats[4p-3 .. 4p] (one dword-aligned 16-B load).  16-B aligned coalesced stores.
+        const int qpr = Cg >> 2;                                   // quads per row
+        const int nq = K * qpr;                                    // quads per centroid
+        const unsigned qmagic = (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u;
+#pragma unroll 1
+        for (int c = 0; c < CPW; ++c) {
+            const int s = s0 + c;
+            if (s >= S) break;
+            const int *lst = mylist + c * lcap;
+            float4 *g4 = reinterpret_cast<float4 *>(grouped + ((size_t)b * S + s) * row_elems);
+            const float ccx = cx2[c / 2][c & 1], ccy = cy2[c / 2][c & 1], ccz = cz2[c / 2][c & 1];
+#pragma unroll 2
+            for (int q = lane; q < nq; q += PN2_WAVE) {
+                const int k = qpr == 1 ? q : (int)__umulhi((unsigned)q, qmagic);   // q / qpr
+                const int part = q - k * qpr;
+                const int j = lst[k];
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (j >= 0) {
+                    const float *row = bp + (size_t)j * D;
+                    if (part == 0) {
+                        const float *pj = bx + (size_t)j * 3;
+                        v = make_float4(pj[0] - ccx, pj[1] - ccy, pj[2] - ccz, row[0]);   // :128, :131
+                    } else {
+                        const float *src = row + (4 * part - 3);
+                        v = make_float4(src[0], src[1], src[2], src[3]);
+                    }
+                }
+                g4[q] = v;
+            }
+        }
+        return;
+    }
+    // Narrow rows: elements of one centroid's [K, 3+D] block are walked 64 at a time (256-B
+    // coalesced stores); BQ_UNROLL independent gathers are issued before the first is consumed.
 #pragma unroll 1
     for (int c = 0; c < CPW; ++c) {
         const int s = s0 + c;
         if (s >= S) break;
-        const int *lst = mylist + c * K;
+        const int *lst = mylist + c * lcap;
         float *g = grouped + ((size_t)b * S + s) * row_elems;
-        const float ccx = cx[c], ccy = cy[c], ccz = cz[c];
+        const float ccx = cx2[c / 2][c & 1], ccy = cy2[c / 2][c & 1], ccz = cz2[c / 2][c & 1];
 #pragma unroll 1
         for (int f0 = 0; f0 < row_elems; f0 += PN2_WAVE * BQ_UNROLL) {
             float v[BQ_UNROLL];
@@ -166,7 +327,7 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
     const int per_wg = WAVES * CPW;
     const int tiles = (S + per_wg - 1) / per_wg;
     const int tile_pts = N < BQ_TILE ? ((N + PN2_WAVE - 1) & ~(PN2_WAVE - 1)) : BQ_TILE;
-    const size_t lds = (size_t)tile_pts * sizeof(float4) + (size_t)WAVES * CPW * K * sizeof(int);
+    const size_t lds = (size_t)tile_pts * sizeof(float4) + (size_t)WAVES * CPW * (K + PN2_WAVE) * sizeof(int);
     const long long nwg = (long long)B * tiles;
     if (nwg > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
     const int Cg = 3 + D;
@@ -179,7 +340,7 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(THREADS), lds, stream, xyz, new_xyz, points, B, N, S, K, D,
-                       r2, tiles, magic, idx, grouped, err_count);
+                       r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
     return PN2_LAUNCH_RC();
 }
 
@@ -198,16 +359,29 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
     if (B == 0) return PN2_OK;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // Many centroids per block: 8 waves x 4 centroids share one LDS image of the block.
-    // Few centroids (deep levels): one centroid per wave, small workgroups, for parallelism.
-    const int cfg = pn2::tune_get("bq_cfg", (long long)B * S >= 8192 ? 0 : 1);
+    // Many centroids per block: the waves of a workgroup share one LDS image of the block and
+    // each takes several centroids.  Few centroids (deep levels): small workgroups, two
+    // centroids per wave, for parallelism.
+    const long long total = (long long)B * S;
+    const int cfg = pn2::tune_get("bq_cfg", total >= 8192 ? 3 : (total >= 2048 ? 1 : 2));
+    // Few centroids with wide rows (deep levels): the gather is latency-bound inside the scan
+    // waves, so the scan kernel writes idx only and a fully parallel elementwise kernel groups.
+    if (grouped && total < 2048 && pn2::tune_get("bq_split", 1)) {
+        int rc = pn2_ball_query_group(radius, nsample, xyz, new_xyz, nullptr, B, N, S, 0, idx, nullptr, err_count, stream_);
+        if (rc != PN2_OK) return rc;
+        return pn2_group_points(xyz, new_xyz, points, idx, B, N, S, nsample, D, grouped, nullptr, stream_);
+    }
+#define PN2_BQ(T, C) return launch_ball_query_group<T, C>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream)
     switch (cfg) {
-        case 0: return launch_ball_query_group<512, 4>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream);
-        case 1: return launch_ball_query_group<256, 1>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream);
-        case 2: return launch_ball_query_group<512, 2>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream);
-        case 3: return launch_ball_query_group<1024, 4>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream);
-        case 4: return launch_ball_query_group<256, 4>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream);
-        case 5: return launch_ball_query_group<512, 8>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream);
+        case 0: PN2_BQ(512, 8);
+        case 1: PN2_BQ(256, 2);
+        case 2: PN2_BQ(128, 2);
+        case 3: PN2_BQ(512, 4);
+        case 4: PN2_BQ(1024, 4);
+        case 5: PN2_BQ(256, 8);
+        case 6: PN2_BQ(1024, 8);
+        case 7: PN2_BQ(256, 4);
         default: return PN2_ERR_UNSUPPORTED;
     }
+#undef PN2_BQ
 }
