@@ -103,6 +103,71 @@ int pn2_three_interpolate(const float *points2, const int64_t *idx3, const float
 int pn2_three_interpolate_backward(const float *grad_out, const int64_t *idx3, const float *weight3,
                                    int B, int N, int S, int D, float *grad_points2, pn2_stream_t stream);
 
+
+/* ---- grouped / pointwise MLP: [Conv 1x1 -> BatchNorm -> ReLU] x n (+ max over nsample) ----------
+ *                                   models/pointnet2_utils.py:196-200 (SA), :312-314 (FP)
+ * Rows are channel-last: M = B*S*K (SA) or B*N (FP) rows of Ci channels.  All GEMMs are exact-fp32
+ * MFMA (v_mfma_f32_32x32x2_f32).  Normalised activations are never stored: a layer writes its raw
+ * conv output Z and the next consumer applies max(scale*z+shift, 0) while loading. */
+
+/* out[M,N] = A * W^T + bias, with
+ *   prologue 0: A = [x1 (K1 cols, pitch ld1) | x2 (K2 cols, pitch ld2)]           (x2 may be NULL)
+ *   prologue 1: A = max(scale[k]*[x1|x2] + shift[k], 0)       previous layer's BatchNorm + ReLU
+ *   prologue 2: A = dz(g = x1, z = x2)  [BatchNorm+ReLU backward of an N_prev = K1 channel layer]:
+ *               gh = (scale*z+shift > 0) ? g : 0;  dz = scale*(gh - c1 - (z-mean)*invstd*c2);
+ *               with argk != NULL, g is the gradient of the max-pooled output [M/pool_k, K1] and
+ *               is routed to row argk (autograd of torch.max over nsample, :200).
+ * W is [N][K] row-major (w_is_kn = 0) or [K][N] (w_is_kn = 1; the weight itself, for dX = dZ * W).
+ * stat_partial (nullable) [pn2_mlp_gemm_max_partials(M)][2][N]: per-workgroup column sums of out
+ * and out^2 (train-mode batch statistics) -- or, when mask_z != NULL (backward), out is first
+ * masked by the ReLU of the layer below (mscale*mask_z+mshift > 0) and the sums are those of
+ * out and out*(mask_z-mmean)*minvstd (its dbeta / dgamma). */
+int pn2_mlp_gemm_max_partials(int M);
+int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
+                 const float *scale, const float *shift, const float *mean, const float *invstd,
+                 const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w,
+                 int ldw, int w_is_kn, const float *bias, float *out, int ldo, int M, int N,
+                 float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
+                 const float *mmean, const float *minvstd, pn2_stream_t stream);
+
+/* partial[P][2][C] -> train-mode BatchNorm coefficients scale = gamma*invstd, shift = beta -
+ * mean*scale (biased variance), mean/invstd for backward, and the running-estimate update
+ * running = (1-momentum)*running + momentum*batch (unbiased variance), nn.BatchNorm semantics. */
+int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma, const float *beta,
+                    float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                    float *shift, float *mean_out, float *invstd_out, pn2_stream_t stream);
+
+/* eval-mode coefficients from the running estimates */
+int pn2_bn_eval_coeff(int C, const float *gamma, const float *beta, const float *running_mean,
+                      const float *running_var, float eps, float *scale, float *shift, pn2_stream_t stream);
+
+/* y = max(scale*z+shift, 0) for [rows_out, C] (pool_k = 0), or max over groups of pool_k
+ * consecutive rows of z [rows_out*pool_k, C] with the winning k in argk (nullable).  C % 4 == 0. */
+int pn2_bn_relu_out(const float *z, long long rows_out, int C, int pool_k, const float *scale,
+                    const float *shift, float *y, unsigned char *argk, pn2_stream_t stream);
+
+/* dW[N][K1+K2] = dz^T * act([x1|x2]), db[N] = column sums of dz (db nullable); dz as in prologue 2
+ * of pn2_mlp_gemm (g, z, argk/pool_k, BatchNorm constants of this layer); act = BatchNorm+ReLU of
+ * the layer below when ascale/ashift are given.  partial: workspace
+ * [pn2_mlp_dw_partials(M)][N][K1+K2+1] floats. */
+int pn2_mlp_dw_partials(int M);
+int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
+               const float *scale, const float *shift, const float *mean, const float *invstd,
+               const float *c1, const float *c2, const float *x1, int ld1, int K1, const float *x2, int ld2,
+               int K2, const float *ascale, const float *ashift, int M, int N, float *partial, float *dw,
+               float *db, pn2_stream_t stream);
+
+/* BatchNorm+ReLU backward statistics of the top layer of a stack: partial
+ * [pn2_bn_bwd_reduce_partials(rows)][2][C] sums of gh and gh*xh over rows (rows = M, or the
+ * M/pool_k pooled rows with argk).  pn2_bn_bwd_finalize turns partials (from here or from the
+ * backward epilogue of pn2_mlp_gemm) into dgamma, dbeta, c1 = dbeta/count, c2 = dgamma/count. */
+int pn2_bn_bwd_reduce_partials(long long rows);
+int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long long rows, int C,
+                      const unsigned char *argk, int pool_k, const float *scale, const float *shift,
+                      const float *mean, const float *invstd, float *partial, pn2_stream_t stream);
+int pn2_bn_bwd_finalize(const float *partial, int P, int C, double count, float *dgamma, float *dbeta,
+                        float *c1, float *c2, pn2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libpn2hip.so")
 
-_vp, _ci, _cl, _cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+_vp, _ci, _cl, _cd, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_float
 
 # name -> argtypes, in the order of include/pn2_hip.h
 SIGNATURES = {
@@ -23,6 +23,18 @@ SIGNATURES = {
     "pn2_three_nn": [_vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
     "pn2_three_interpolate_backward": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
+    "pn2_mlp_gemm_max_partials": [_ci],
+    "pn2_mlp_gemm": [_vp, _ci, _ci, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _ci, _vp,
+                     _vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
+    "pn2_bn_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_bn_eval_coeff": [_ci, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp],
+    "pn2_bn_relu_out": [_vp, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "pn2_mlp_dw_partials": [_ci],
+    "pn2_mlp_dw": [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _ci, _ci, _vp, _vp,
+                   _ci, _ci, _vp, _vp, _vp, _vp],
+    "pn2_bn_bwd_reduce_partials": [_cl],
+    "pn2_bn_bwd_reduce": [_vp, _ci, _vp, _ci, _cl, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_bn_bwd_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

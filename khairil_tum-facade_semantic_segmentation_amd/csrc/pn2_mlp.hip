@@ -1,0 +1,729 @@
+// Grouped / pointwise MLP of PointNetSetAbstraction and PointNetFeaturePropagation on gfx950:
+// the [Conv 1x1 -> BatchNorm -> ReLU] x n (+ max over nsample) stacks of
+// models/pointnet2_utils.py:196-200 and :312-314, as exact-fp32 MFMA GEMMs over channel-last
+// rows (M = B*S*K or B*N rows, Ci -> Co channels).
+//
+//   Z = act(X) * W^T + bias          v_mfma_f32_32x32x2_f32, 128-row x BN-column tiles
+//   act(x) = max(scale[c]*x + shift[c], 0)   the PREVIOUS layer's BatchNorm+ReLU, applied while
+//                                            the tile is staged (the normalised activation is
+//                                            never written to HBM)
+//   epilogue: per-channel sum(z), sum(z^2) of this layer (train-mode batch statistics), kept in
+//             registers across a workgroup's tiles -> one partial per workgroup (deterministic)
+//
+// These layers are HBM-bound (Ci, Co <= 512 against M up to 524288): the design goal is one
+// read of the producer's raw output and one write of ours per layer.  MFMA operand mapping
+// (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k] and B[k][j=l&31] with k taken from
+// its half (l>>5) of the staged K chunk, so each lane reads CONSECUTIVE k with ds_read_b128.
+#include <math.h>
+
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_BM = 128;       // rows per tile (4 waves x 32)
+constexpr int MLP_BK = 32;        // K chunk staged per step
+constexpr int MLP_LD = MLP_BK + 4;  // LDS row pitch in floats: 144 B keeps ds_read_b128 conflict-free
+constexpr int MLP_THREADS = 256;
+
+enum { PRO_NONE = 0, PRO_BN_RELU = 1, PRO_BN_BWD = 2 };
+// PRO_BN_BWD with argk != null: g[row,c] = (argk[row/pool_k, c] == row%pool_k) ? x1[row/pool_k, c] : 0
+// (the gradient of torch.max over nsample, models/pointnet2_utils.py:200, never materialised).
+
+struct GemmArgs {
+    // A = [X1 (K1 cols) | X2 (K2 cols)], row-major with row pitches ld1 / ld2 (X2 may be null)
+    const float *x1, *x2;
+    int ld1, ld2, K1, K2;
+    // PRO_BN_RELU: a = max(scale[k]*x + shift[k], 0) over the concatenated K axis
+    // PRO_BN_BWD : a = dz computed from (g = x1, z = x2, both [M,K1]):
+    //              gh = (scale*z+shift > 0) ? g : 0; xh = (z-mean)*invstd; dz = scale*(gh - c1 - xh*c2)
+    const float *scale, *shift, *mean, *invstd, *c1, *c2;
+    const unsigned char *argk;    // [M/pool_k][K1] or null
+    int pool_k;
+    // B: W is [N][K] row-major (wt == 0) or [K][N] row-major (wt == 1)
+    const float *w;
+    int ldw, wt;
+    const float *bias;            // [N] or null
+    float *out;                   // [M][N], pitch ldo
+    int ldo, M, N, K;
+    float *stat_partial;          // [gridDim.x][2][N] or null: column sums of out and out^2
+    // backward epilogue (mask_z != null): out = (mscale*zprev+mshift > 0) ? out : 0 ; partials of
+    // sum(out) and sum(out * (zprev-mmean)*minvstd) go to stat_partial instead
+    const float *mask_z, *mscale, *mshift, *mmean, *minvstd;
+    int ldm;
+};
+
+template <int BN, int PRO, bool VEC4>
+__global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
+{
+    constexpr int NB = BN / 32;                       // 32-column accumulator blocks per wave
+    __shared__ __attribute__((aligned(16))) float sA[MLP_BM * MLP_LD];
+    __shared__ __attribute__((aligned(16))) float sB[BN * MLP_LD];
+    __shared__ float sRed[4][2][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int col0 = blockIdx.y * BN;
+    const int ntiles = (p.M + MLP_BM - 1) / MLP_BM;
+    const bool bwd_epi = p.mask_z != nullptr;
+
+    float csum[NB], csq[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) { csum[cb] = 0.0f; csq[cb] = 0.0f; }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * MLP_BM;
+        f32x16 acc[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+
+        for (int k0 = 0; k0 < p.K; k0 += MLP_BK) {
+            // ---- stage A chunk [128 x 32] ------------------------------------------------
+            if (VEC4) {
+#pragma unroll
+                for (int i = 0; i < (MLP_BM * MLP_BK / 4) / MLP_THREADS; ++i) {
+                    const int e = tid + i * MLP_THREADS;
+                    const int r = e >> 3, c4 = (e & 7) * 4;
+                    const int row = row0 + r, k = k0 + c4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < p.M && k < p.K) {
+                        if (PRO == PRO_BN_BWD) {
+                            float4 g;
+                            if (p.argk) {
+                                const int cent = row / p.pool_k, kk = row - cent * p.pool_k;
+                                const uchar4 ak = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.K1 + k);
+                                const float4 go = *reinterpret_cast<const float4 *>(p.x1 + (size_t)cent * p.ld1 + k);
+                                g = make_float4(ak.x == kk ? go.x : 0.f, ak.y == kk ? go.y : 0.f, ak.z == kk ? go.z : 0.f,
+                                                ak.w == kk ? go.w : 0.f);
+                            } else {
+                                g = *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k);
+                            }
+                            const float4 z = *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + k);
+                            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + k);
+                            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + k);
+                            const float4 mu = *reinterpret_cast<const float4 *>(p.mean + k);
+                            const float4 is = *reinterpret_cast<const float4 *>(p.invstd + k);
+                            const float4 a1 = *reinterpret_cast<const float4 *>(p.c1 + k);
+                            const float4 a2 = *reinterpret_cast<const float4 *>(p.c2 + k);
+#define PN2_DZ(f) v.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                            PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                        } else {
+                            v = k < p.K1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k)
+                                         : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k - p.K1));
+                            if (PRO == PRO_BN_RELU) {
+                                const float4 sc = *reinterpret_cast<const float4 *>(p.scale + k);
+                                const float4 sh = *reinterpret_cast<const float4 *>(p.shift + k);
+                                v.x = fmaxf(sc.x * v.x + sh.x, 0.f);
+                                v.y = fmaxf(sc.y * v.y + sh.y, 0.f);
+                                v.z = fmaxf(sc.z * v.z + sh.z, 0.f);
+                                v.w = fmaxf(sc.w * v.w + sh.w, 0.f);
+                            }
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(&sA[r * MLP_LD + c4]) = v;
+                }
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < (MLP_BM * MLP_BK) / MLP_THREADS; ++i) {
+                    const int e = tid + i * MLP_THREADS;
+                    const int r = e >> 5, c = e & 31;
+                    const int row = row0 + r, k = k0 + c;
+                    float v = 0.f;
+                    if (row < p.M && k < p.K) {
+                        if (PRO == PRO_BN_BWD) {
+                            float g;
+                            if (p.argk) {
+                                const int cent = row / p.pool_k, kk = row - cent * p.pool_k;
+                                g = p.argk[(size_t)cent * p.K1 + k] == kk ? p.x1[(size_t)cent * p.ld1 + k] : 0.f;
+                            } else {
+                                g = p.x1[(size_t)row * p.ld1 + k];
+                            }
+                            const float z = p.x2[(size_t)row * p.ld2 + k];
+                            const float sc = p.scale[k];
+                            v = sc * (((sc * z + p.shift[k]) > 0.f ? g : 0.f) - p.c1[k] - (z - p.mean[k]) * p.invstd[k] * p.c2[k]);
+                        } else {
+                            v = k < p.K1 ? p.x1[(size_t)row * p.ld1 + k] : p.x2[(size_t)row * p.ld2 + (k - p.K1)];
+                            if (PRO == PRO_BN_RELU) v = fmaxf(p.scale[k] * v + p.shift[k], 0.f);
+                        }
+                    }
+                    sA[r * MLP_LD + c] = v;
+                }
+            }
+            // ---- stage B chunk as [BN cols][32 k] ------------------------------------------
+            if (p.wt == 0) {
+                if (VEC4 && (p.ldw & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < (BN * MLP_BK / 4 + MLP_THREADS - 1) / MLP_THREADS; ++i) {
+                        const int e = tid + i * MLP_THREADS;
+                        if (e < BN * MLP_BK / 4) {
+                            const int r = e >> 3, c4 = (e & 7) * 4;
+                            const int n = col0 + r, k = k0 + c4;
+                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (n < p.N && k < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k);
+                            *reinterpret_cast<float4 *>(&sB[r * MLP_LD + c4]) = v;
+                        }
+                    }
+                } else {
+                    for (int e = tid; e < BN * MLP_BK; e += MLP_THREADS) {
+                        const int r = e >> 5, c = e & 31;
+                        const int n = col0 + r, k = k0 + c;
+                        sB[r * MLP_LD + c] = (n < p.N && k < p.K) ? p.w[(size_t)n * p.ldw + k] : 0.f;
+                    }
+                }
+            } else {   // W given as [K][N]: read along N (coalesced), transpose into LDS
+                for (int e = tid; e < BN * MLP_BK; e += MLP_THREADS) {
+                    const int c = e / BN, r = e - c * BN;              // c: k within chunk, r: column
+                    const int n = col0 + r, k = k0 + c;
+                    sB[r * MLP_LD + c] = (n < p.N && k < p.K) ? p.w[(size_t)k * p.ldw + n] : 0.f;
+                }
+            }
+            __syncthreads();
+            // ---- MFMA: each lane owns k = 16*half + t of the chunk -------------------------
+            const float *aRow = &sA[(wave * 32 + l31) * MLP_LD + 16 * half];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(&sB[(cb * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[cb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*half ----------
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int col = col0 + cb * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+            float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
+            if (bwd_epi) { ms = p.mscale[col]; mh = p.mshift[col]; mm = p.mmean[col]; mi = p.minvstd[col]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= p.M) continue;
+                float z = acc[cb][r] + bv;
+                if (bwd_epi) {
+                    const float zp = p.mask_z[(size_t)row * p.ldm + col];
+                    z = (ms * zp + mh) > 0.f ? z : 0.f;
+                    csum[cb] += z;
+                    csq[cb] += z * ((zp - mm) * mi);
+                } else {
+                    csum[cb] += z;
+                    csq[cb] += z * z;
+                }
+                p.out[(size_t)row * p.ldo + col] = z;
+            }
+        }
+    }
+    if (!p.stat_partial) return;
+    // ---- per-workgroup partial statistics ---------------------------------------------------
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        float s = csum[cb] + __shfl_xor(csum[cb], 32);
+        float q = csq[cb] + __shfl_xor(csq[cb], 32);
+        if (half == 0) { sRed[wave][0][cb * 32 + l31] = s; sRed[wave][1][cb * 32 + l31] = q; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * BN; e += MLP_THREADS) {
+        const int which = e / BN, c = e - which * BN;
+        if (col0 + c < p.N) {
+            const float v = (sRed[0][which][c] + sRed[1][which][c]) + (sRed[2][which][c] + sRed[3][which][c]);
+            p.stat_partial[((size_t)blockIdx.x * 2 + which) * p.N + col0 + c] = v;
+        }
+    }
+}
+
+// partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
+// :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
+// estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
+// double in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int P, int C, double count,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float momentum, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, float *__restrict__ scale,
+                                                          float *__restrict__ shift, float *__restrict__ mean_out,
+                                                          float *__restrict__ invstd_out)
+{
+    __shared__ double sS[8][32], sQ[8][32];
+    const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 8 partial slices
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int i = py; i < P; i += 8) {
+            s += (double)partial[((size_t)i * 2 + 0) * C + c];
+            q += (double)partial[((size_t)i * 2 + 1) * C + c];
+        }
+    sS[py][cl] = s;
+    sQ[py][cl] = q;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+    for (int i = 1; i < 8; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    scale[c] = g * invstd;
+    shift[c] = b - (float)mean * g * invstd;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (invstd_out) invstd_out[c] = invstd;
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval-mode coefficients from the running estimates
+__global__ __launch_bounds__(256) void bn_eval_coeff_kernel(int C, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
+                                                            const float *__restrict__ running_mean,
+                                                            const float *__restrict__ running_var, float eps,
+                                                            float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    scale[c] = g * invstd;
+    shift[c] = b - running_mean[c] * g * invstd;
+}
+
+// y[r, c] = max(scale[c]*z[r,c] + shift[c], 0), optionally max-pooled over groups of K rows
+// (torch.max(new_points, 2)[0], models/pointnet2_utils.py:200) with the winning k recorded.
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_out_kernel(const float *__restrict__ z, long long rows_out, int C, int K,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, float *__restrict__ y,
+                                                          unsigned char *__restrict__ argk)
+{
+    const int c4n = C >> 2;
+    const long long total = rows_out * c4n;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long ro = t / c4n;
+        const int c = (int)(t - ro * c4n) * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        if (!POOL) {
+            const float4 v = *reinterpret_cast<const float4 *>(z + (size_t)ro * C + c);
+            float4 o;
+            o.x = fmaxf(sc.x * v.x + sh.x, 0.f);
+            o.y = fmaxf(sc.y * v.y + sh.y, 0.f);
+            o.z = fmaxf(sc.z * v.z + sh.z, 0.f);
+            o.w = fmaxf(sc.w * v.w + sh.w, 0.f);
+            *reinterpret_cast<float4 *>(y + (size_t)ro * C + c) = o;
+        } else {
+            float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            uchar4 bk = make_uchar4(0, 0, 0, 0);
+            const float *base = z + (size_t)ro * K * C + c;
+            for (int k = 0; k < K; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)k * C);
+                const float ox = fmaxf(sc.x * v.x + sh.x, 0.f), oy = fmaxf(sc.y * v.y + sh.y, 0.f);
+                const float oz = fmaxf(sc.z * v.z + sh.z, 0.f), ow = fmaxf(sc.w * v.w + sh.w, 0.f);
+                if (ox > best.x) { best.x = ox; bk.x = (unsigned char)k; }      // first maximum wins, like torch.max
+                if (oy > best.y) { best.y = oy; bk.y = (unsigned char)k; }
+                if (oz > best.z) { best.z = oz; bk.z = (unsigned char)k; }
+                if (ow > best.w) { best.w = ow; bk.w = (unsigned char)k; }
+            }
+            *reinterpret_cast<float4 *>(y + (size_t)ro * C + c) = best;
+            if (argk) *reinterpret_cast<uchar4 *>(argk + (size_t)ro * C + c) = bk;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// dW[n][k] = sum_m dz[m][n] * a[m][k]   (+ column Kact == bias gradient: a[m][Kact] := 1)
+// dz comes from the PRO_BN_BWD formula (explicit g or pooled g), a = act(x) like the forward A
+// operand.  Output block 64(n) x 64(k) per workgroup; each wave reduces its own 32 rows of every
+// 128-row tile (MFMA k-axis = m), the 4 waves are summed through LDS at the end, and every
+// workgroup writes one partial [Co][Kact+1] slab (summed in fixed order by dw_reduce_kernel).
+struct DwArgs {
+    const float *g, *z;             // dz sources: g [M][N] (or pooled [M/pool_k][N]), z [M][N]
+    int ldg, ldz;
+    const float *scale, *shift, *mean, *invstd, *c1, *c2;   // of THIS layer (N channels)
+    const unsigned char *argk;
+    int pool_k;
+    const float *x1, *x2;           // activation sources of the layer input, [M][K1] | [M][K2]
+    int ld1, ld2, K1, K2;
+    const float *ascale, *ashift;   // previous layer's BN coefficients (null: input is already an activation)
+    float *partial;                 // [gridDim.x][N][K1+K2+1]
+    int M, N;
+};
+
+constexpr int DW_BN = 64, DW_BK = 64, DW_LD = 68;
+
+__global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float sD[MLP_BM * DW_LD];     // dz tile   [128 m][64 n]
+    __shared__ __attribute__((aligned(16))) float sX[MLP_BM * DW_LD];     // act tile  [128 m][64 k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.y * DW_BN, k0 = blockIdx.z * DW_BK;
+    const int Kact = p.K1 + p.K2, Kout = Kact + 1;
+    const int ntiles = (p.M + MLP_BM - 1) / MLP_BM;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * MLP_BM;
+        for (int e = tid; e < MLP_BM * 64; e += MLP_THREADS) {
+            const int r = e >> 6, c = e & 63;
+            const int row = row0 + r;
+            float dv = 0.f, xv = 0.f;
+            if (row < p.M) {
+                const int n = n0 + c;
+                if (n < p.N) {
+                    float g;
+                    if (p.argk) {
+                        const int cent = row / p.pool_k, kk = row - cent * p.pool_k;
+                        g = p.argk[(size_t)cent * p.N + n] == kk ? p.g[(size_t)cent * p.ldg + n] : 0.f;
+                    } else {
+                        g = p.g[(size_t)row * p.ldg + n];
+                    }
+                    const float z = p.z[(size_t)row * p.ldz + n];
+                    const float sc = p.scale[n];
+                    dv = sc * (((sc * z + p.shift[n]) > 0.f ? g : 0.f) - p.c1[n] - (z - p.mean[n]) * p.invstd[n] * p.c2[n]);
+                }
+                const int k = k0 + c;
+                if (k < Kact) {
+                    xv = k < p.K1 ? p.x1[(size_t)row * p.ld1 + k] : p.x2[(size_t)row * p.ld2 + (k - p.K1)];
+                    if (p.ascale) xv = fmaxf(p.ascale[k] * xv + p.ashift[k], 0.f);
+                } else if (k == Kact) {
+                    xv = 1.0f;                                   // bias-gradient column
+                }
+            }
+            sD[r * DW_LD + c] = dv;
+            sX[r * DW_LD + c] = xv;
+        }
+        __syncthreads();
+        // MFMA: i = n (dz column), j = k (act column), reduction over this wave's 32 rows
+        const float *dBase = &sD[(wave * 32 + 16 * half) * DW_LD];
+        const float *xBase = &sX[(wave * 32 + 16 * half) * DW_LD];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float a0 = dBase[t * DW_LD + l31], a1 = dBase[t * DW_LD + 32 + l31];
+            const float b0 = xBase[t * DW_LD + l31], b1 = xBase[t * DW_LD + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // cross-wave sum through LDS (reuse sD as [4 waves][64 n][64 k] is too big: do it in two passes)
+    float *red = sD;                                             // [64][DW_LD] accumulator image
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int k = b * 32 + l31;
+                        if (w == 0) red[n * DW_LD + k] = acc[a][b][r];
+                        else red[n * DW_LD + k] += acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = p.partial + (size_t)blockIdx.x * p.N * Kout;
+    for (int e = tid; e < 64 * 64; e += MLP_THREADS) {
+        const int n = e >> 6, k = e & 63;
+        if (n0 + n < p.N && k0 + k < Kout) out[(size_t)(n0 + n) * Kout + k0 + k] = red[n * DW_LD + k];
+    }
+}
+
+// dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order.
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
+                                                        float *__restrict__ dw, float *__restrict__ db)
+{
+    const int Kout = K + 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * Kout) return;
+    float s = 0.f;
+    for (int i = 0; i < P; ++i) s += partial[(size_t)i * N * Kout + e];
+    const int n = e / Kout, k = e - n * Kout;
+    if (k < K) dw[(size_t)n * K + k] = s;
+    else if (db) db[n] = s;
+}
+
+// Column partial sums of gh and gh*xh over rows for the TOP layer of a stack (the inner layers
+// get theirs from the GEMM's backward epilogue):  gh = (scale*z+shift > 0) ? g : 0,
+// xh = (z-mean)*invstd.  Explicit g [M][C], or pooled: only the arg-max row of every centroid
+// carries gradient, so the sum runs over centroids with a gather of z.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ g, int ldg,
+                                                            const float *__restrict__ z, int ldz, long long rows,
+                                                            int C, const unsigned char *__restrict__ argk, int pool_k,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            float *__restrict__ partial)
+{
+    __shared__ float sS[8][32], sQ[8][32];
+    const int cl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.y * 32 + cl;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (long long r = (long long)blockIdx.x * 8 + ry; r < rows; r += (long long)gridDim.x * 8) {
+            const float gv = g[(size_t)r * ldg + c];
+            const long long zr = argk ? r * pool_k + argk[(size_t)r * C + c] : r;
+            const float zv = z[(size_t)zr * ldz + c];
+            const float gh = (sc * zv + sh) > 0.f ? gv : 0.f;
+            s += gh;
+            q += gh * ((zv - mu) * is);
+        }
+    }
+    sS[ry][cl] = s;
+    sQ[ry][cl] = q;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        for (int i = 1; i < 8; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+    }
+}
+
+// partial[P][2][C] -> dbeta = sum gh, dgamma = sum gh*xh, c1 = dbeta/count, c2 = dgamma/count
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int P, int C,
+                                                              double count, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, float *__restrict__ c1,
+                                                              float *__restrict__ c2)
+{
+    __shared__ double sS[8][32], sQ[8][32];
+    const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int i = py; i < P; i += 8) {
+            s += (double)partial[((size_t)i * 2 + 0) * C + c];
+            q += (double)partial[((size_t)i * 2 + 1) * C + c];
+        }
+    sS[py][cl] = s;
+    sQ[py][cl] = q;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+    for (int i = 1; i < 8; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    c1[c] = (float)(s / count);
+    c2[c] = (float)(q / count);
+}
+
+inline unsigned grid_for(long long total, int threads)
+{
+    long long blocks = (total + threads - 1) / threads;
+    const long long cap = 256LL * 16;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+template <int BN>
+int launch_gemm(const GemmArgs &a, int pro, bool vec4, int gx, hipStream_t stream)
+{
+    dim3 grid((unsigned)gx, (unsigned)((a.N + BN - 1) / BN));
+#define PN2_GEMM(P, V) hipLaunchKernelGGL((mlp_gemm_kernel<BN, P, V>), grid, dim3(MLP_THREADS), 0, stream, a)
+    if (pro == PRO_NONE) { if (vec4) PN2_GEMM(PRO_NONE, true); else PN2_GEMM(PRO_NONE, false); }
+    else if (pro == PRO_BN_RELU) { if (vec4) PN2_GEMM(PRO_BN_RELU, true); else PN2_GEMM(PRO_BN_RELU, false); }
+    else { if (vec4) PN2_GEMM(PRO_BN_BWD, true); else PN2_GEMM(PRO_BN_BWD, false); }
+#undef PN2_GEMM
+    return PN2_LAUNCH_RC();
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+PN2_EXPORT int pn2_mlp_gemm_max_partials(int M)
+{
+    const int ntiles = (M + MLP_BM - 1) / MLP_BM;
+    return ntiles < 512 ? (ntiles < 1 ? 1 : ntiles) : 512;
+}
+
+PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
+                            const float *scale, const float *shift, const float *mean, const float *invstd,
+                            const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w, int ldw,
+                            int w_is_kn,
+                            const float *bias, float *out, int ldo, int M, int N, float *stat_partial,
+                            const float *mask_z, int ldm, const float *mscale, const float *mshift,
+                            const float *mmean, const float *minvstd, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(x1);
+    PN2_REQUIRE_PTR(w);
+    PN2_REQUIRE_PTR(out);
+    if (M < 0 || N <= 0 || K1 <= 0 || K2 < 0 || ld1 < K1 || ldo < N) return PN2_ERR_SHAPE;
+    if (prologue < PRO_NONE || prologue > PRO_BN_BWD) return PN2_ERR_SHAPE;
+    if (prologue == PRO_BN_BWD) {
+        if (!x2 || !scale || !shift || !mean || !invstd || !c1 || !c2) return PN2_ERR_NULL;
+        if (K2 != K1 || ld2 < K1 || (argk && pool_k <= 0)) return PN2_ERR_SHAPE;
+    } else {
+        if (K2 > 0 && (!x2 || ld2 < K2)) return PN2_ERR_NULL;
+        if (prologue == PRO_BN_RELU && (!scale || !shift)) return PN2_ERR_NULL;
+    }
+    if (mask_z && (!mscale || !mshift || !mmean || !minvstd || ldm < N)) return PN2_ERR_NULL;
+    if (M == 0) return PN2_OK;
+    GemmArgs a;
+    a.x1 = x1; a.x2 = x2; a.ld1 = ld1; a.ld2 = ld2; a.K1 = K1; a.K2 = K2;
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = c1; a.c2 = c2;
+    a.argk = prologue == PRO_BN_BWD ? argk : nullptr; a.pool_k = pool_k;
+    a.w = w; a.ldw = ldw; a.wt = w_is_kn; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N;
+    a.K = prologue == PRO_BN_BWD ? K1 : K1 + K2;
+    a.stat_partial = stat_partial;
+    a.mask_z = mask_z; a.mscale = mscale; a.mshift = mshift; a.mmean = mmean; a.minvstd = minvstd; a.ldm = ldm;
+    // float4 staging needs 16-B aligned rows and a concat boundary on a multiple of 4
+    bool vec4 = (ld1 % 4 == 0) && aligned16(x1) && (K1 % 4 == 0) && (a.K % 4 == 0);
+    if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
+    if (prologue != PRO_NONE) vec4 = vec4 && aligned16(scale) && aligned16(shift);
+    if (prologue == PRO_BN_BWD) vec4 = vec4 && aligned16(mean) && aligned16(invstd) && aligned16(c1) && aligned16(c2);
+    const int gx = pn2_mlp_gemm_max_partials(M);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N <= 32) return launch_gemm<32>(a, prologue, vec4, gx, stream);
+    if (N <= 64) return launch_gemm<64>(a, prologue, vec4, gx, stream);
+    return launch_gemm<128>(a, prologue, vec4, gx, stream);
+}
+
+PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *scale, float *shift, float *mean_out, float *invstd_out,
+                               pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(partial);
+    PN2_REQUIRE_PTR(scale);
+    PN2_REQUIRE_PTR(shift);
+    if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_), partial,
+                       P, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
+                       invstd_out);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_bn_eval_coeff(int C, const float *gamma, const float *beta, const float *running_mean,
+                                 const float *running_var, float eps, float *scale, float *shift,
+                                 pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(running_mean);
+    PN2_REQUIRE_PTR(running_var);
+    PN2_REQUIRE_PTR(scale);
+    PN2_REQUIRE_PTR(shift);
+    if (C <= 0) return PN2_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), C,
+                       gamma, beta, running_mean, running_var, eps, scale, shift);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_bn_relu_out(const float *z, long long rows_out, int C, int pool_k, const float *scale,
+                               const float *shift, float *y, unsigned char *argk, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(z);
+    PN2_REQUIRE_PTR(scale);
+    PN2_REQUIRE_PTR(shift);
+    PN2_REQUIRE_PTR(y);
+    if (rows_out < 0 || C <= 0 || pool_k < 0 || pool_k > 255) return PN2_ERR_SHAPE;
+    if (C % 4 != 0 || !aligned16(z) || !aligned16(y) || !aligned16(scale) || !aligned16(shift)) return PN2_ERR_UNSUPPORTED;
+    if (rows_out == 0) return PN2_OK;
+    const long long total = rows_out * (C / 4);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (pool_k > 0)
+        hipLaunchKernelGGL(bn_relu_out_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, stream, z, rows_out, C,
+                           pool_k, scale, shift, y, argk);
+    else
+        hipLaunchKernelGGL(bn_relu_out_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, stream, z, rows_out, C, 1,
+                           scale, shift, y, argk);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_mlp_dw_partials(int M)
+{
+    const int ntiles = (M + MLP_BM - 1) / MLP_BM;
+    return ntiles < 64 ? (ntiles < 1 ? 1 : ntiles) : 64;
+}
+
+PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
+                          const float *scale, const float *shift, const float *mean, const float *invstd,
+                          const float *c1, const float *c2, const float *x1, int ld1, int K1, const float *x2,
+                          int ld2, int K2, const float *ascale, const float *ashift, int M, int N,
+                          float *partial, float *dw, float *db, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(g);
+    PN2_REQUIRE_PTR(z);
+    PN2_REQUIRE_PTR(scale);
+    PN2_REQUIRE_PTR(shift);
+    PN2_REQUIRE_PTR(mean);
+    PN2_REQUIRE_PTR(invstd);
+    PN2_REQUIRE_PTR(c1);
+    PN2_REQUIRE_PTR(c2);
+    PN2_REQUIRE_PTR(x1);
+    PN2_REQUIRE_PTR(partial);
+    PN2_REQUIRE_PTR(dw);
+    if (M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !x2) || (argk && pool_k <= 0)) return PN2_ERR_SHAPE;
+    if ((ascale == nullptr) != (ashift == nullptr)) return PN2_ERR_NULL;
+    DwArgs a;
+    a.g = g; a.z = z; a.ldg = ldg; a.ldz = ldz; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+    a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.x1 = x1; a.x2 = x2; a.ld1 = ld1; a.ld2 = ld2;
+    a.K1 = K1; a.K2 = K2; a.ascale = ascale; a.ashift = ashift; a.partial = partial; a.M = M; a.N = N;
+    const int K = K1 + K2, P = pn2_mlp_dw_partials(M);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    dim3 grid((unsigned)P, (unsigned)((N + DW_BN - 1) / DW_BN), (unsigned)((K + 1 + DW_BK - 1) / DW_BK));
+    hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(MLP_THREADS), 0, stream, a);
+    int rc = PN2_LAUNCH_RC();
+    if (rc != PN2_OK) return rc;
+    const int total = N * (K + 1);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, P, N, K, dw, db);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_bn_bwd_reduce_partials(long long rows)
+{
+    const long long b = (rows + 63) / 64;
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+PN2_EXPORT int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long long rows, int C,
+                                 const unsigned char *argk, int pool_k, const float *scale, const float *shift,
+                                 const float *mean, const float *invstd, float *partial, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(g);
+    PN2_REQUIRE_PTR(z);
+    PN2_REQUIRE_PTR(scale);
+    PN2_REQUIRE_PTR(shift);
+    PN2_REQUIRE_PTR(mean);
+    PN2_REQUIRE_PTR(invstd);
+    PN2_REQUIRE_PTR(partial);
+    if (rows <= 0 || C <= 0 || (argk && pool_k <= 0)) return PN2_ERR_SHAPE;
+    dim3 grid((unsigned)pn2_bn_bwd_reduce_partials(rows), (unsigned)((C + 31) / 32));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g, ldg, z, ldz, rows,
+                       C, argk, pool_k, scale, shift, mean, invstd, partial);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_bn_bwd_finalize(const float *partial, int P, int C, double count, float *dgamma, float *dbeta,
+                                   float *c1, float *c2, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(partial);
+    PN2_REQUIRE_PTR(c1);
+    PN2_REQUIRE_PTR(c2);
+    if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       partial, P, C, count, dgamma, dbeta, c1, c2);
+    return PN2_LAUNCH_RC();
+}

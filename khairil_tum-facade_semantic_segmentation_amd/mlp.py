@@ -1,0 +1,198 @@
+"""Fused [Conv 1x1 -> BatchNorm -> ReLU] x n (+ max over nsample) stacks on the MFMA kernels of
+csrc/pn2_mlp.hip (C ABI: pn2_mlp_gemm / pn2_bn_* / pn2_mlp_dw in include/pn2_hip.h).
+
+Reference semantics: models/pointnet2_utils.py:196-200 (set abstraction) and :312-314 (feature
+propagation) with nn.BatchNorm2d/1d in train or eval mode.  torch supplies memory and autograd
+bookkeeping only; every FLOP of the stack runs in the HIP library."""
+import torch
+
+from . import _lib
+from .ops import _dev, _ptr, _stream
+
+PRO_NONE, PRO_BN_RELU, PRO_BN_BWD = 0, 1, 2
+
+
+def _gemm(lib, dev, x1, K1, x2, K2, pro, consts, argk, pool_k, w, ldw, w_is_kn, bias, out, M, N, stat=None,
+          mask=None):
+    """Thin positional wrapper of pn2_mlp_gemm.  consts = (scale, shift, mean, invstd, c1, c2) or None;
+    mask = (mask_z, mscale, mshift, mmean, minvstd) or None."""
+    c = consts or (None,) * 6
+    m = mask or (None,) * 5
+    rc = lib.pn2_mlp_gemm(_ptr(x1), x1.stride(0), K1, _ptr(x2), 0 if x2 is None else x2.stride(0), K2, pro,
+                          _ptr(c[0]), _ptr(c[1]), _ptr(c[2]), _ptr(c[3]), _ptr(c[4]), _ptr(c[5]),
+                          _ptr(argk), pool_k, _ptr(w), ldw, w_is_kn, _ptr(bias), _ptr(out), out.stride(0), M, N,
+                          _ptr(stat), _ptr(m[0]), 0 if m[0] is None else m[0].stride(0), _ptr(m[1]), _ptr(m[2]),
+                          _ptr(m[3]), _ptr(m[4]), _stream(dev))
+    _lib.check(rc, "pn2_mlp_gemm")
+
+
+class _MLPStack(torch.autograd.Function):
+    """y = stack(x1 | x2).  args: bns (list of nn.BatchNorm modules, for running stats / mode),
+    pool_k (0 = no pooling), x1 [M,K1], x2 [M,K2] or None, then per layer conv_w, conv_b, bn_w, bn_b."""
+
+    @staticmethod
+    def forward(ctx, bns, pool_k, x1, x2, *params):
+        dev = _dev(x1, x2)
+        lib = _lib.load()
+        L = len(bns)
+        M, K1 = x1.shape
+        K2 = 0 if x2 is None else x2.shape[1]
+        training = bns[0].training
+        f32 = dict(dtype=torch.float32, device=dev)
+        zs, coefs = [], []
+        with torch.cuda.device(dev):
+            for l in range(L):
+                w, b, gamma, beta = params[4 * l:4 * l + 4]
+                Co = w.shape[0]
+                w2 = w.reshape(Co, -1)
+                z = torch.empty((M, Co), **f32)
+                P = lib.pn2_mlp_gemm_max_partials(M)
+                stat = torch.empty((P, 2, Co), **f32) if training else None
+                if l == 0:
+                    _gemm(lib, dev, x1, K1, x2, K2, PRO_NONE, None, None, 0, w2, w2.stride(0), 0, b, z, M, Co, stat)
+                else:
+                    zp = zs[-1]
+                    sc, sh = coefs[-1][0], coefs[-1][1]
+                    _gemm(lib, dev, zp, zp.shape[1], None, 0, PRO_BN_RELU, (sc, sh, None, None, None, None), None, 0,
+                          w2, w2.stride(0), 0, b, z, M, Co, stat)
+                scale, shift = torch.empty(Co, **f32), torch.empty(Co, **f32)
+                bn = bns[l]
+                if training:
+                    mean, invstd = torch.empty(Co, **f32), torch.empty(Co, **f32)
+                    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    rc = lib.pn2_bn_finalize(_ptr(stat), P, Co, float(M), _ptr(gamma), _ptr(beta), float(bn.eps), mom,
+                                             _ptr(bn.running_mean) if track else None,
+                                             _ptr(bn.running_var) if track else None, _ptr(scale), _ptr(shift),
+                                             _ptr(mean), _ptr(invstd), _stream(dev))
+                    _lib.check(rc, "pn2_bn_finalize")
+                    if track and bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                    coefs.append((scale, shift, mean, invstd))
+                else:
+                    rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
+                                               float(bn.eps), _ptr(scale), _ptr(shift), _stream(dev))
+                    _lib.check(rc, "pn2_bn_eval_coeff")
+                    coefs.append((scale, shift, None, None))
+                zs.append(z)
+            Co = zs[-1].shape[1]
+            if pool_k:
+                rows_out = M // pool_k
+                y = torch.empty((rows_out, Co), **f32)
+                argk = torch.empty((rows_out, Co), dtype=torch.uint8, device=dev)
+            else:
+                rows_out = M
+                y = torch.empty((M, Co), **f32)
+                argk = None
+            rc = lib.pn2_bn_relu_out(_ptr(zs[-1]), rows_out, Co, pool_k, _ptr(coefs[-1][0]), _ptr(coefs[-1][1]), _ptr(y),
+                                     _ptr(argk), _stream(dev))
+            _lib.check(rc, "pn2_bn_relu_out")
+        ctx.training = training
+        ctx.pool_k = pool_k
+        ctx.L = L
+        ctx.has_x2 = x2 is not None
+        ctx.argk = argk
+        ctx.coefs = coefs
+        ctx.zs = zs
+        ctx.save_for_backward(x1, *((x2,) if x2 is not None else ()), *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.training:
+            raise NotImplementedError("backward through an eval-mode (running-statistics) BatchNorm stack is not "
+                                      "built; the reference only back-propagates in train mode")
+        saved = ctx.saved_tensors
+        x1 = saved[0]
+        x2 = saved[1] if ctx.has_x2 else None
+        params = saved[2 if ctx.has_x2 else 1:]
+        L, pool_k, zs, coefs, argk = ctx.L, ctx.pool_k, ctx.zs, ctx.coefs, ctx.argk
+        dev = gy.device
+        lib = _lib.load()
+        M, K1 = x1.shape
+        K2 = 0 if x2 is None else x2.shape[1]
+        f32 = dict(dtype=torch.float32, device=dev)
+        gy = gy.to(torch.float32).contiguous()
+        grads = [None] * (4 * L)
+        with torch.cuda.device(dev):
+            # BatchNorm+ReLU backward statistics of the top layer
+            zt = zs[-1]
+            Ct = zt.shape[1]
+            sc, sh, mu, istd = coefs[-1]
+            rows = gy.shape[0]
+            P = lib.pn2_bn_bwd_reduce_partials(rows)
+            part = torch.empty((P, 2, Ct), **f32)
+            rc = lib.pn2_bn_bwd_reduce(_ptr(gy), gy.stride(0), _ptr(zt), zt.stride(0), rows, Ct, _ptr(argk), pool_k,
+                                       _ptr(sc), _ptr(sh), _ptr(mu), _ptr(istd), _ptr(part), _stream(dev))
+            _lib.check(rc, "pn2_bn_bwd_reduce")
+            g = gy
+            g_argk = argk
+            for l in range(L - 1, -1, -1):
+                w, b = params[4 * l], params[4 * l + 1]
+                Co = w.shape[0]
+                w2 = w.reshape(Co, -1)
+                Ci = w2.shape[1]
+                z = zs[l]
+                sc, sh, mu, istd = coefs[l]
+                dgamma, dbeta = torch.empty(Co, **f32), torch.empty(Co, **f32)
+                c1, c2 = torch.empty(Co, **f32), torch.empty(Co, **f32)
+                rc = lib.pn2_bn_bwd_finalize(_ptr(part), P, Co, float(M), _ptr(dgamma), _ptr(dbeta), _ptr(c1), _ptr(c2),
+                                             _stream(dev))
+                _lib.check(rc, "pn2_bn_bwd_finalize")
+                grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
+                consts = (sc, sh, mu, istd, c1, c2)
+                # dW, db
+                Pw = lib.pn2_mlp_dw_partials(M)
+                wpart = torch.empty((Pw, Co, Ci + 1), **f32)
+                dw, db = torch.empty((Co, Ci), **f32), torch.empty(Co, **f32)
+                if l == 0:
+                    a1, a2, ak1, ak2, asc, ash = x1, x2, K1, K2, None, None
+                else:
+                    a1, a2, ak1, ak2 = zs[l - 1], None, zs[l - 1].shape[1], 0
+                    asc, ash = coefs[l - 1][0], coefs[l - 1][1]
+                rc = lib.pn2_mlp_dw(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(g_argk), pool_k if g_argk is not None else 0,
+                                    _ptr(sc), _ptr(sh), _ptr(mu), _ptr(istd), _ptr(c1), _ptr(c2), _ptr(a1), a1.stride(0), ak1,
+                                    _ptr(a2), 0 if a2 is None else a2.stride(0), ak2, _ptr(asc), _ptr(ash), M, Co, _ptr(wpart),
+                                    _ptr(dw), _ptr(db), _stream(dev))
+                _lib.check(rc, "pn2_mlp_dw")
+                grads[4 * l], grads[4 * l + 1] = dw.view_as(w), db
+                # dX (= gradient w.r.t. the activation below), masked + reduced for the layer below
+                if l > 0:
+                    zp = zs[l - 1]
+                    psc, psh, pmu, pistd = coefs[l - 1]
+                    gp = torch.empty((M, Ci), **f32)
+                    P = lib.pn2_mlp_gemm_max_partials(M)
+                    part = torch.empty((P, 2, Ci), **f32)
+                    _gemm(lib, dev, g, Co, z, Co, PRO_BN_BWD, consts, g_argk, pool_k if g_argk is not None else 0, w2,
+                          w2.stride(0), 1, None, gp, M, Ci, part, (zp, psc, psh, pmu, pistd))
+                    g, g_argk = gp, None
+                else:
+                    gx1 = gx2 = None
+                    need1 = ctx.needs_input_grad[2]
+                    need2 = ctx.has_x2 and ctx.needs_input_grad[3]
+                    if need1 or need2:
+                        gx = torch.empty((M, Ci), **f32)
+                        _gemm(lib, dev, g, Co, z, Co, PRO_BN_BWD, consts, g_argk, pool_k if g_argk is not None else 0, w2,
+                              w2.stride(0), 1, None, gx, M, Ci)
+                        gx1 = gx[:, :K1] if need1 else None
+                        gx2 = gx[:, K1:] if need2 else None
+        return (None, None, gx1, gx2) + tuple(grads)
+
+
+def mlp_stack(x1, x2, convs, bns, pool_k=0):
+    """Run [conv -> bn -> relu] x len(convs) on rows [x1 | x2] ([M,K1], [M,K2] or None); with
+    pool_k > 0 the output is max-pooled over groups of pool_k consecutive rows."""
+    _dev(x1, x2)
+    x1 = x1.to(torch.float32)
+    if x1.stride(-1) != 1:
+        x1 = x1.contiguous()
+    if x2 is not None:
+        x2 = x2.to(torch.float32)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+    params = []
+    for conv, bn in zip(convs, bns):
+        if conv.bias is None or bn.weight is None or bn.bias is None:
+            raise NotImplementedError("mlp_stack expects conv bias and affine BatchNorm (as the reference builds them)")
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return _MLPStack.apply(list(bns), pool_k, x1, x2, *params)

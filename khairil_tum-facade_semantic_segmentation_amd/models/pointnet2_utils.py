@@ -16,7 +16,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+import os
+
+from .. import mlp, ops
 
 _FPS_START_QUEUE = []
 
@@ -93,10 +95,24 @@ def sample_and_group_all(xyz, points):
     return new_xyz, grouped
 
 
+# PN2_TORCH_MLP=1 routes the conv/BN/ReLU stacks through torch ops (rocBLAS + ATen BatchNorm)
+# instead of the MFMA kernels of csrc/pn2_mlp.hip: an A/B switch for benchmarks and tests.
+_TORCH_MLP = os.environ.get("PN2_TORCH_MLP", "0") == "1"
+
+
+def _mlp(x1, x2, convs, bns, pool_k=0):
+    """[rows, K1] | [rows, K2] -> [rows(/pool_k), Cout] through the fused HIP stack."""
+    if _TORCH_MLP:
+        x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        y = _pointwise_mlp(x, convs, bns)
+        return y.reshape(-1, pool_k, y.shape[-1]).max(dim=1)[0] if pool_k else y
+    return mlp.mlp_stack(x1, x2, convs, bns, pool_k)
+
+
 def _pointwise_mlp(x, convs, bns):
-    """[rows, Cin] -> [rows, Cout]: (1x1 conv -> BatchNorm -> ReLU) per layer on channel-last
-    rows.  The conv weights keep the reference's [Co,Ci,1(,1)] shapes; BN statistics run over
-    all rows, which is exactly BatchNorm2d over (B,K,S) / BatchNorm1d over (B,N)."""
+    """torch-op form of the stack (A/B reference): (1x1 conv -> BatchNorm -> ReLU) per layer on
+    channel-last rows; BN statistics run over all rows, which is exactly BatchNorm2d over (B,K,S)
+    / BatchNorm1d over (B,N)."""
     for conv, bn in zip(convs, bns):
         w = conv.weight.reshape(conv.weight.shape[0], -1)
         x = torch.addmm(conv.bias, x, w.t()) if conv.bias is not None else x @ w.t()
@@ -127,8 +143,8 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)
         B, S, K, C = grouped.shape
-        y = _pointwise_mlp(grouped.reshape(B * S * K, C), self.mlp_convs, self.mlp_bns)
-        return new_xyz, y.reshape(B, S, K, -1).max(dim=2)[0]
+        y = _mlp(grouped.reshape(B * S * K, C), None, self.mlp_convs, self.mlp_bns, pool_k=K)   # :196-200
+        return new_xyz, y.reshape(B, S, -1)
 
     def forward(self, xyz, points):
         """xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
@@ -161,8 +177,8 @@ class PointNetSetAbstractionMsg(nn.Module):             # reference :205-262
             if points is not None:                       # multi-scale variant orders [feats, xyz] (:248)
                 g = torch.cat([g[..., 3:], g[..., :3]], dim=-1)
             B, S, _, C = g.shape
-            y = _pointwise_mlp(g.reshape(B * S * K, C), convs, bns)
-            scales.append(y.reshape(B, S, K, -1).max(dim=2)[0])
+            y = _mlp(g.reshape(B * S * K, C), None, convs, bns, pool_k=K)
+            scales.append(y.reshape(B, S, -1))
         return new_xyz.permute(0, 2, 1), torch.cat(scales, dim=-1).permute(0, 2, 1)
 
 
@@ -185,8 +201,11 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
         else:
             idx3, w3 = ops.three_nn(xyz1, xyz2)         # :296-302
             interpolated = ops.three_interpolate(points2, idx3, w3)   # :303
-        x = interpolated if points1 is None else torch.cat([points1, interpolated], dim=-1)   # :305-309
-        y = _pointwise_mlp(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns)
+        D2 = interpolated.shape[-1]
+        if points1 is None:                             # :305-309 (the concat is never materialised)
+            y = _mlp(interpolated.reshape(B * N, D2), None, self.mlp_convs, self.mlp_bns)
+        else:
+            y = _mlp(points1.reshape(B * N, -1), interpolated.reshape(B * N, D2), self.mlp_convs, self.mlp_bns)
         return y.reshape(B, N, -1)
 
     def forward(self, xyz1, xyz2, points1, points2):

@@ -1,0 +1,115 @@
+"""GPU numerics of the fused MFMA MLP stack (csrc/pn2_mlp.hip through the C ABI) against a plain
+PyTorch fp32 reference of the same op: [Conv 1x1 -> BatchNorm -> ReLU] x n (+ max over nsample),
+train mode (batch statistics, running-stat update, full backward) and eval mode."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    from khairil_tum_facade_semantic_segmentation_amd import _lib, mlp
+    _lib.load()
+    return torch, mlp
+
+
+def make_stack(torch, cin, widths, seed):
+    g = torch.Generator().manual_seed(seed)
+    convs, bns = torch.nn.ModuleList(), torch.nn.ModuleList()
+    last = cin
+    for co in widths:
+        conv = torch.nn.Conv1d(last, co, 1)
+        bn = torch.nn.BatchNorm1d(co, momentum=0.1)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (last + co)) ** 0.5)
+            conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
+            bn.weight.copy_(torch.rand(co, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(co, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(co, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(co, generator=g) + 0.5)
+        convs.append(conv)
+        bns.append(bn)
+        last = co
+    return convs, bns
+
+
+def torch_reference(torch, x, convs, bns, pool_k):
+    h = x.t().unsqueeze(0)                       # [1, C, M]
+    for conv, bn in zip(convs, bns):
+        h = torch.relu(bn(conv(h)))
+    y = h.squeeze(0).t()                         # [M, Co]
+    if pool_k:
+        y = y.reshape(-1, pool_k, y.shape[-1]).max(dim=1)[0]
+    return y
+
+
+CASES = [
+    # M, K1, K2, widths, pool_k
+    (4096, 12, 0, (32, 32, 64), 32),             # SA1 shape
+    (2048, 67, 0, (64, 64, 128), 32),            # SA2: odd input width -> scalar staging
+    (1024, 259, 0, (256, 256, 512), 32),         # SA4: wide, multi column-block
+    (1000, 64, 256, (256, 128), 0),              # FP2: two sources, ragged M
+    (640, 128, 0, (128, 128, 128), 0),           # FP1
+    (96, 7, 5, (20, 36), 8),                     # everything ragged / tiny
+]
+
+
+@pytest.mark.parametrize("M,K1,K2,widths,pool_k", CASES)
+def test_stack_train_forward_backward(env, M, K1, K2, widths, pool_k):
+    import copy
+    torch, mlp = env
+    convs, bns = make_stack(torch, K1 + K2, widths, seed=M + K1)
+    rconvs, rbns = copy.deepcopy(convs).cuda().train(), copy.deepcopy(bns).cuda().train()
+    convs, bns = convs.cuda().train(), bns.cuda().train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, K1 + K2, generator=g).cuda()
+    # duplicate some rows inside a pooling group: ties in the max must not break gradients
+    if pool_k:
+        x[1] = x[0]
+    x1 = x[:, :K1].contiguous().requires_grad_(True)
+    x2 = x[:, K1:].contiguous().requires_grad_(True) if K2 else None
+    xr = x.clone().requires_grad_(True)
+
+    y = mlp.mlp_stack(x1, x2, convs, bns, pool_k)
+    yr = torch_reference(torch, xr, rconvs, rbns, pool_k)
+    assert y.shape == yr.shape
+    scale = float(yr.detach().abs().max()) + 1e-6
+    assert float((y - yr).detach().abs().max()) <= 2e-4 * scale + 1e-5
+
+    go = torch.randn(y.shape, generator=g).cuda()
+    y.backward(go)
+    yr.backward(go)
+    gx = x1.grad if x2 is None else torch.cat([x1.grad, x2.grad], dim=1)
+    def close(a, b, what):
+        s = float(b.abs().max()) + 1e-6
+        err = float((a - b).abs().max())
+        assert err <= 2e-3 * s + 1e-5, (what, err, s)
+    close(gx, xr.grad, "dx")
+    for l, (c, rc, b, rb) in enumerate(zip(convs, rconvs, bns, rbns)):
+        close(c.weight.grad, rc.weight.grad, "dW%d" % l)
+        close(b.weight.grad, rb.weight.grad, "dgamma%d" % l)
+        close(b.bias.grad, rb.bias.grad, "dbeta%d" % l)
+        # conv bias feeds a train-mode BatchNorm: its true gradient is 0, both sides hold noise
+        assert float(c.bias.grad.abs().max()) <= 1e-3 * (float(go.abs().sum()) ** 0.5 + 1.0)
+        close(b.running_mean, rb.running_mean, "running_mean%d" % l)
+        close(b.running_var, rb.running_var, "running_var%d" % l)
+        assert int(b.num_batches_tracked) == int(rb.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("M,K1,K2,widths,pool_k", CASES)
+def test_stack_eval_forward(env, M, K1, K2, widths, pool_k):
+    import copy
+    torch, mlp = env
+    convs, bns = make_stack(torch, K1 + K2, widths, seed=7 * M + K2)
+    convs, bns = convs.cuda().eval(), bns.cuda().eval()
+    x = torch.randn(M, K1 + K2, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        y = mlp.mlp_stack(x[:, :K1].contiguous(), x[:, K1:].contiguous() if K2 else None, convs, bns, pool_k)
+        yr = torch_reference(torch, x, convs, bns, pool_k)
+    scale = float(yr.abs().max()) + 1e-6
+    assert float((y - yr).abs().max()) <= 1e-4 * scale + 1e-5
+    assert int(bns[0].num_batches_tracked) == 0
