@@ -149,8 +149,8 @@ int pn2_bn_relu_out(const float *z, long long rows_out, int C, int pool_k, const
 /* dW[N][K1+K2] = dz^T * act([x1|x2]), db[N] = column sums of dz (db nullable); dz as in prologue 2
  * of pn2_mlp_gemm (g, z, argk/pool_k, BatchNorm constants of this layer); act = BatchNorm+ReLU of
  * the layer below when ascale/ashift are given.  partial: workspace
- * [pn2_mlp_dw_partials(M)][N][K1+K2+1] floats. */
-int pn2_mlp_dw_partials(int M);
+ * [pn2_mlp_dw_partials(M, N, K1+K2)][N][K1+K2+1] floats. */
+int pn2_mlp_dw_partials(int M, int N, int K);
 int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
                const float *scale, const float *shift, const float *mean, const float *invstd,
                const float *c1, const float *c2, const float *x1, int ld1, int K1, const float *x2, int ld2,

@@ -366,6 +366,10 @@ struct DwArgs {
 
 constexpr int DW_BN = 64, DW_BK = 64, DW_LD = 68;
 
+// VEC4: every row pitch / column split is a multiple of 4 floats and 16-B aligned, so a thread
+// owns 4 fixed columns (its BatchNorm constants live in registers for the whole kernel) and
+// stages 8 rows of them per tile with float4 loads, all issued before the first is consumed.
+template <bool VEC4>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 {
     __shared__ __attribute__((aligned(16))) float sD[MLP_BM * DW_LD];     // dz tile   [128 m][64 n]
@@ -382,36 +386,118 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // per-thread column constants (VEC4 path)
+    const int c4 = (tid & 15) * 4, rb = tid >> 4;
+    const int n4 = n0 + c4, k4 = k0 + c4;
+    const bool n_ok = n4 < p.N;                      // N % 4 == 0 on this path
+    const bool k_act = k4 < Kact, k_one = k4 == Kact;
+    const bool from1 = k4 < p.K1;
+    float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, is = sc, a1 = sc, a2 = sc, asc = sc, ash = sc;
+    if (VEC4) {
+        if (n_ok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n4);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n4);
+            mu = *reinterpret_cast<const float4 *>(p.mean + n4);
+            is = *reinterpret_cast<const float4 *>(p.invstd + n4);
+            a1 = *reinterpret_cast<const float4 *>(p.c1 + n4);
+            a2 = *reinterpret_cast<const float4 *>(p.c2 + n4);
+        }
+        if (k_act && p.ascale) {
+            asc = *reinterpret_cast<const float4 *>(p.ascale + k4);
+            ash = *reinterpret_cast<const float4 *>(p.ashift + k4);
+        }
+    }
+
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * MLP_BM;
-        for (int e = tid; e < MLP_BM * 64; e += MLP_THREADS) {
-            const int r = e >> 6, c = e & 63;
-            const int row = row0 + r;
-            float dv = 0.f, xv = 0.f;
-            if (row < p.M) {
-                const int n = n0 + c;
-                if (n < p.N) {
-                    float g;
+        if (VEC4) {
+            float4 gv[8], zv[8], xv[8];
+            uchar4 av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = row0 + rb + 16 * i;
+                const bool rok = row < p.M;
+                gv[i] = zv[i] = xv[i] = make_float4(0, 0, 0, 0);
+                av[i] = make_uchar4(255, 255, 255, 255);
+                if (rok && n_ok) {
                     if (p.argk) {
-                        const int cent = row / p.pool_k, kk = row - cent * p.pool_k;
-                        g = p.argk[(size_t)cent * p.N + n] == kk ? p.g[(size_t)cent * p.ldg + n] : 0.f;
+                        const int cent = row / p.pool_k;
+                        gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4);
+                        av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4);
                     } else {
-                        g = p.g[(size_t)row * p.ldg + n];
+                        gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4);
                     }
-                    const float z = p.z[(size_t)row * p.ldz + n];
-                    const float sc = p.scale[n];
-                    dv = sc * (((sc * z + p.shift[n]) > 0.f ? g : 0.f) - p.c1[n] - (z - p.mean[n]) * p.invstd[n] * p.c2[n]);
+                    zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4);
                 }
-                const int k = k0 + c;
-                if (k < Kact) {
-                    xv = k < p.K1 ? p.x1[(size_t)row * p.ld1 + k] : p.x2[(size_t)row * p.ld2 + (k - p.K1)];
-                    if (p.ascale) xv = fmaxf(p.ascale[k] * xv + p.ashift[k], 0.f);
-                } else if (k == Kact) {
-                    xv = 1.0f;                                   // bias-gradient column
-                }
+                if (rok && k_act)
+                    xv[i] = from1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k4)
+                                  : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k4 - p.K1));
             }
-            sD[r * DW_LD + c] = dv;
-            sX[r * DW_LD + c] = xv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = rb + 16 * i;
+                const int row = row0 + r;
+                float4 dv = make_float4(0, 0, 0, 0), av4 = make_float4(0, 0, 0, 0);
+                if (row < p.M) {
+                    if (n_ok) {
+                        float4 g = gv[i];
+                        if (p.argk) {
+                            const int kk = row % p.pool_k;
+                            g.x = av[i].x == kk ? g.x : 0.f;
+                            g.y = av[i].y == kk ? g.y : 0.f;
+                            g.z = av[i].z == kk ? g.z : 0.f;
+                            g.w = av[i].w == kk ? g.w : 0.f;
+                        }
+                        const float4 z = zv[i];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                        PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                    }
+                    if (k_act) {
+                        av4 = xv[i];
+                        if (p.ascale) {
+                            av4.x = fmaxf(asc.x * av4.x + ash.x, 0.f);
+                            av4.y = fmaxf(asc.y * av4.y + ash.y, 0.f);
+                            av4.z = fmaxf(asc.z * av4.z + ash.z, 0.f);
+                            av4.w = fmaxf(asc.w * av4.w + ash.w, 0.f);
+                        }
+                    } else if (k_one) {
+                        av4.x = 1.0f;                            // bias-gradient column
+                    }
+                }
+                *reinterpret_cast<float4 *>(&sD[r * DW_LD + c4]) = dv;
+                *reinterpret_cast<float4 *>(&sX[r * DW_LD + c4]) = av4;
+            }
+        } else {
+            for (int e = tid; e < MLP_BM * 64; e += MLP_THREADS) {
+                const int r = e >> 6, c = e & 63;
+                const int row = row0 + r;
+                float dv = 0.f, xv = 0.f;
+                if (row < p.M) {
+                    const int n = n0 + c;
+                    if (n < p.N) {
+                        float g;
+                        if (p.argk) {
+                            const int cent = row / p.pool_k, kk = row - cent * p.pool_k;
+                            g = p.argk[(size_t)cent * p.N + n] == kk ? p.g[(size_t)cent * p.ldg + n] : 0.f;
+                        } else {
+                            g = p.g[(size_t)row * p.ldg + n];
+                        }
+                        const float z = p.z[(size_t)row * p.ldz + n];
+                        const float s1 = p.scale[n];
+                        dv = s1 * (((s1 * z + p.shift[n]) > 0.f ? g : 0.f) - p.c1[n] - (z - p.mean[n]) * p.invstd[n] * p.c2[n]);
+                    }
+                    const int k = k0 + c;
+                    if (k < Kact) {
+                        xv = k < p.K1 ? p.x1[(size_t)row * p.ld1 + k] : p.x2[(size_t)row * p.ld2 + (k - p.K1)];
+                        if (p.ascale) xv = fmaxf(p.ascale[k] * xv + p.ashift[k], 0.f);
+                    } else if (k == Kact) {
+                        xv = 1.0f;                               // bias-gradient column
+                    }
+                }
+                sD[r * DW_LD + c] = dv;
+                sX[r * DW_LD + c] = xv;
+            }
         }
         __syncthreads();
         // MFMA: i = n (dz column), j = k (act column), reduction over this wave's 32 rows
@@ -419,16 +505,16 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
         const float *xBase = &sX[(wave * 32 + 16 * half) * DW_LD];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float a0 = dBase[t * DW_LD + l31], a1 = dBase[t * DW_LD + 32 + l31];
+            const float a0 = dBase[t * DW_LD + l31], a1v = dBase[t * DW_LD + 32 + l31];
             const float b0 = xBase[t * DW_LD + l31], b1 = xBase[t * DW_LD + 32 + l31];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
-    // cross-wave sum through LDS (reuse sD as [4 waves][64 n][64 k] is too big: do it in two passes)
+    // cross-wave sum through LDS
     float *red = sD;                                             // [64][DW_LD] accumulator image
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -453,15 +539,23 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
     }
 }
 
-// dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order.
+// dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order:
+// 32 elements x 8 partial slices per workgroup, slices combined in order through LDS.
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
                                                         float *__restrict__ dw, float *__restrict__ db)
 {
+    __shared__ float sS[8][32];
     const int Kout = K + 1;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N * Kout) return;
+    const int el = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const size_t stride = (size_t)N * Kout;
     float s = 0.f;
-    for (int i = 0; i < P; ++i) s += partial[(size_t)i * N * Kout + e];
+    if (e < N * Kout)
+        for (int i = py; i < P; i += 8) s += partial[(size_t)i * stride + e];
+    sS[py][el] = s;
+    __syncthreads();
+    if (py != 0 || e >= N * Kout) return;
+    for (int i = 1; i < 8; ++i) s += sS[i][el];
     const int n = e / Kout, k = e - n * Kout;
     if (k < K) dw[(size_t)n * K + k] = s;
     else if (db) db[n] = s;
@@ -652,10 +746,15 @@ PN2_EXPORT int pn2_bn_relu_out(const float *z, long long rows_out, int C, int po
     return PN2_LAUNCH_RC();
 }
 
-PN2_EXPORT int pn2_mlp_dw_partials(int M)
+PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
 {
+    // ~1024 workgroups in flight: the M axis is split so that (M slabs) x (64x64 output blocks) ~ 1024
     const int ntiles = (M + MLP_BM - 1) / MLP_BM;
-    return ntiles < 64 ? (ntiles < 1 ? 1 : ntiles) : 64;
+    const int blocks = ((N + DW_BN - 1) / DW_BN) * ((K + 1 + DW_BK - 1) / DW_BK);
+    int p = 1024 / (blocks < 1 ? 1 : blocks);
+    if (p < 8) p = 8;
+    if (p > ntiles) p = ntiles;
+    return p < 1 ? 1 : p;
 }
 
 PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
@@ -681,14 +780,21 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     a.g = g; a.z = z; a.ldg = ldg; a.ldz = ldz; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
     a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.x1 = x1; a.x2 = x2; a.ld1 = ld1; a.ld2 = ld2;
     a.K1 = K1; a.K2 = K2; a.ascale = ascale; a.ashift = ashift; a.partial = partial; a.M = M; a.N = N;
-    const int K = K1 + K2, P = pn2_mlp_dw_partials(M);
+    const int K = K1 + K2, P = pn2_mlp_dw_partials(M, N, K);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     dim3 grid((unsigned)P, (unsigned)((N + DW_BN - 1) / DW_BN), (unsigned)((K + 1 + DW_BK - 1) / DW_BK));
-    hipLaunchKernelGGL(mlp_dw_kernel, grid, dim3(MLP_THREADS), 0, stream, a);
+    bool vec4 = (N % 4 == 0) && (ldg % 4 == 0) && (ldz % 4 == 0) && (K1 % 4 == 0) && (ld1 % 4 == 0) && (K % 4 == 0) &&
+                aligned16(g) && aligned16(z) && aligned16(x1) && aligned16(scale) && aligned16(shift) &&
+                aligned16(mean) && aligned16(invstd) && aligned16(c1) && aligned16(c2);
+    if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
+    if (ascale) vec4 = vec4 && aligned16(ascale) && aligned16(ashift);
+    if (argk) vec4 = vec4 && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
+    if (vec4) hipLaunchKernelGGL(mlp_dw_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(mlp_dw_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK) return rc;
     const int total = N * (K + 1);
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, P, N, K, dw, db);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, partial, P, N, K, dw, db);
     return PN2_LAUNCH_RC();
 }
 

@@ -142,7 +142,7 @@ class _MLPStack(torch.autograd.Function):
                 grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
                 consts = (sc, sh, mu, istd, c1, c2)
                 # dW, db
-                Pw = lib.pn2_mlp_dw_partials(M)
+                Pw = lib.pn2_mlp_dw_partials(M, Co, Ci)
                 wpart = torch.empty((Pw, Co, Ci + 1), **f32)
                 dw, db = torch.empty((Co, Ci), **f32), torch.empty(Co, **f32)
                 if l == 0:
