@@ -245,31 +245,264 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined form of mlp_gemm_kernel for the all-float4 case.  A workgroup's (tile,
+// K-chunk) steps form one flat sequence; while the MFMAs of step s run, the global loads of step
+// s+1 (across tile boundaries too) are already in flight into registers, and are transformed
+// (BatchNorm/ReLU prologue or the dz formula) and written to LDS after the barrier.
+// WT: the weight is given [K][N] (dX = dZ * W); its tile is staged k-major and read with
+// ds_read_b32 (lanes along N: conflict-free) instead of being transposed.
+template <int BN, int PRO, bool WT>
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs p, int pool_shift)
+{
+    constexpr int NB = BN / 32;
+    constexpr int LDBT = BN + 4;
+    constexpr int SB_ELEMS = WT ? MLP_BK * LDBT : BN * MLP_LD;
+    __shared__ __attribute__((aligned(16))) float sA[MLP_BM * MLP_LD];
+    __shared__ __attribute__((aligned(16))) float sB[SB_ELEMS];
+    __shared__ float sRed[4][2][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int col0 = blockIdx.y * BN;
+    const int ntiles = (p.M + MLP_BM - 1) / MLP_BM;
+    const int nk = (p.K + MLP_BK - 1) / MLP_BK;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nsteps = my_tiles * nk;
+    const bool bwd_epi = p.mask_z != nullptr;
+    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: rows ar + 32*i, 4 columns at ac4
+
+    float4 ra[4], rz[4], rb[NB];
+    uchar4 rk[4];
+    float4 cs, ch, cm, ci, cc1, cc2;
+    cs = ch = cm = ci = cc1 = cc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto issue = [&](int step) {
+        const int t = step / nk, kc = step - t * nk;
+        const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM, k0 = kc * MLP_BK;
+        const int k = k0 + ac4;
+        const bool kok = k < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + ar + 32 * i;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PRO == PRO_BN_BWD) { rz[i] = ra[i]; rk[i] = make_uchar4(255, 255, 255, 255); }
+            if (row < p.M && kok) {
+                if (PRO == PRO_BN_BWD) {
+                    if (p.argk) {
+                        const int cent = pool_shift >= 0 ? (row >> pool_shift) : row / p.pool_k;
+                        ra[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)cent * p.ld1 + k);
+                        rk[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.K1 + k);
+                    } else {
+                        ra[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k);
+                    }
+                    rz[i] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + k);
+                } else {
+                    ra[i] = k < p.K1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k)
+                                     : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k - p.K1));
+                }
+            }
+        }
+        if (PRO != PRO_NONE && kok) {
+            cs = *reinterpret_cast<const float4 *>(p.scale + k);
+            ch = *reinterpret_cast<const float4 *>(p.shift + k);
+            if (PRO == PRO_BN_BWD) {
+                cm = *reinterpret_cast<const float4 *>(p.mean + k);
+                ci = *reinterpret_cast<const float4 *>(p.invstd + k);
+                cc1 = *reinterpret_cast<const float4 *>(p.c1 + k);
+                cc2 = *reinterpret_cast<const float4 *>(p.c2 + k);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + i * MLP_THREADS;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!WT) {
+                const int r = e >> 3, c4 = (e & 7) * 4;              // [BN cols][32 k]
+                if (col0 + r < p.N && k0 + c4 < p.K)
+                    rb[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)(col0 + r) * p.ldw + k0 + c4);
+            } else {
+                const int kk = e / (BN / 4), c4 = (e - kk * (BN / 4)) * 4;   // [32 k][BN cols]
+                if (k0 + kk < p.K && col0 + c4 < p.N)
+                    rb[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)(k0 + kk) * p.ldw + col0 + c4);
+            }
+        }
+    };
+
+    auto commit = [&](int step) {
+        const int t = step / nk;
+        const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            if (PRO == PRO_BN_RELU) {
+                v.x = fmaxf(cs.x * v.x + ch.x, 0.f);
+                v.y = fmaxf(cs.y * v.y + ch.y, 0.f);
+                v.z = fmaxf(cs.z * v.z + ch.z, 0.f);
+                v.w = fmaxf(cs.w * v.w + ch.w, 0.f);
+                // rows past M / columns past K were loaded as 0 and must stay 0 (shift may be > 0)
+                const int row = row0 + ar + 32 * i;
+                if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (PRO == PRO_BN_BWD) {
+                float4 g = ra[i];
+                const float4 z = rz[i];
+                if (p.argk) {
+                    const int row = row0 + ar + 32 * i;
+                    const int kk = pool_shift >= 0 ? (row & ((1 << pool_shift) - 1)) : row % p.pool_k;
+                    g.x = rk[i].x == kk ? g.x : 0.f;
+                    g.y = rk[i].y == kk ? g.y : 0.f;
+                    g.z = rk[i].z == kk ? g.z : 0.f;
+                    g.w = rk[i].w == kk ? g.w : 0.f;
+                }
+#define PN2_DZ(f) v.f = cs.f * (((cs.f * z.f + ch.f) > 0.f ? g.f : 0.f) - cc1.f - (z.f - cm.f) * ci.f * cc2.f)
+                PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                const int row = row0 + ar + 32 * i;
+                if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4 *>(&sA[(ar + 32 * i) * MLP_LD + ac4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + i * MLP_THREADS;
+            if (!WT) {
+                const int r = e >> 3, c4 = (e & 7) * 4;
+                *reinterpret_cast<float4 *>(&sB[r * MLP_LD + c4]) = rb[i];
+            } else {
+                const int kk = e / (BN / 4), c4 = (e - kk * (BN / 4)) * 4;
+                *reinterpret_cast<float4 *>(&sB[kk * LDBT + c4]) = rb[i];
+            }
+        }
+    };
+
+    float csum[NB], csq[NB];
+    f32x16 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        csum[cb] = 0.0f;
+        csq[cb] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+    }
+
+    if (nsteps > 0) issue(0);
+    for (int step = 0; step < nsteps; ++step) {
+        commit(step);
+        __syncthreads();
+        if (step + 1 < nsteps) issue(step + 1);                  // next step's loads fly under the MFMAs
+        const float *aRow = &sA[(wave * 32 + l31) * MLP_LD + 16 * half];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                float4 b4;
+                if (!WT) {
+                    b4 = *reinterpret_cast<const float4 *>(&sB[(cb * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
+                } else {
+                    const float *bp = &sB[(16 * half + 4 * q) * LDBT + cb * 32 + l31];
+                    b4 = make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
+                }
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[cb], 0, 0, 0);
+            }
+        }
+        const int t = step / nk, kc = step - t * nk;
+        if (kc == nk - 1) {
+            // ---- epilogue of this tile: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
+            const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM;
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                const int col = col0 + cb * 32 + l31;
+                if (col < p.N) {
+                    const float bv = p.bias ? p.bias[col] : 0.f;
+                    float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
+                    float zp[16];
+                    if (bwd_epi) {
+                        ms = p.mscale[col]; mh = p.mshift[col]; mm = p.mmean[col]; mi = p.minvstd[col];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            zp[r] = row < p.M ? p.mask_z[(size_t)row * p.ldm + col] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (row < p.M) {
+                            float z = acc[cb][r] + bv;
+                            if (bwd_epi) {
+                                z = (ms * zp[r] + mh) > 0.f ? z : 0.f;
+                                csum[cb] += z;
+                                csq[cb] += z * ((zp[r] - mm) * mi);
+                            } else {
+                                csum[cb] += z;
+                                csq[cb] += z * z;
+                            }
+                            p.out[(size_t)row * p.ldo + col] = z;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+    if (!p.stat_partial) return;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        float s = csum[cb] + __shfl_xor(csum[cb], 32);
+        float q = csq[cb] + __shfl_xor(csq[cb], 32);
+        if (half == 0) { sRed[wave][0][cb * 32 + l31] = s; sRed[wave][1][cb * 32 + l31] = q; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * BN; e += MLP_THREADS) {
+        const int which = e / BN, c = e - which * BN;
+        if (col0 + c < p.N) {
+            const float v = (sRed[0][which][c] + sRed[1][which][c]) + (sRed[2][which][c] + sRed[3][which][c]);
+            p.stat_partial[((size_t)blockIdx.x * 2 + which) * p.N + col0 + c] = v;
+        }
+    }
+}
+
 // partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
 // :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
 // estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
 // double in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int P, int C, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partial, int P, int C, double count,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           float eps, float momentum, float *__restrict__ running_mean,
                                                           float *__restrict__ running_var, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ mean_out,
                                                           float *__restrict__ invstd_out)
 {
-    __shared__ double sS[8][32], sQ[8][32];
-    const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 8 partial slices
+    __shared__ double sS[32][33], sQ[32][33];
+    const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 32 partial slices
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int i = py; i < P; i += 8) {
-            s += (double)partial[((size_t)i * 2 + 0) * C + c];
-            q += (double)partial[((size_t)i * 2 + 1) * C + c];
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;            // <= 16 terms each: fp32 is exact enough here
+        int i = py;
+        for (; i + 32 < P; i += 64) {
+            s0 += partial[((size_t)i * 2 + 0) * C + c];
+            q0 += partial[((size_t)i * 2 + 1) * C + c];
+            s1 += partial[((size_t)(i + 32) * 2 + 0) * C + c];
+            q1 += partial[((size_t)(i + 32) * 2 + 1) * C + c];
         }
+        if (i < P) {
+            s0 += partial[((size_t)i * 2 + 0) * C + c];
+            q0 += partial[((size_t)i * 2 + 1) * C + c];
+        }
+        s = (double)s0 + (double)s1;
+        q = (double)q0 + (double)q1;
+    }
     sS[py][cl] = s;
     sQ[py][cl] = q;
     __syncthreads();
     if (py != 0 || c >= C) return;
-    for (int i = 1; i < 8; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
+    for (int i = 1; i < 32; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -541,21 +774,29 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 
 // dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order:
 // 32 elements x 8 partial slices per workgroup, slices combined in order through LDS.
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
+__global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
                                                         float *__restrict__ dw, float *__restrict__ db)
 {
-    __shared__ float sS[8][32];
+    __shared__ float sS[32][33];
     const int Kout = K + 1;
     const int el = threadIdx.x & 31, py = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
     const size_t stride = (size_t)N * Kout;
     float s = 0.f;
-    if (e < N * Kout)
-        for (int i = py; i < P; i += 8) s += partial[(size_t)i * stride + e];
+    if (e < N * Kout) {
+        float s0 = 0.f, s1 = 0.f;
+        int i = py;
+        for (; i + 32 < P; i += 64) {
+            s0 += partial[(size_t)i * stride + e];
+            s1 += partial[(size_t)(i + 32) * stride + e];
+        }
+        if (i < P) s0 += partial[(size_t)i * stride + e];
+        s = s0 + s1;
+    }
     sS[py][el] = s;
     __syncthreads();
     if (py != 0 || e >= N * Kout) return;
-    for (int i = 1; i < 8; ++i) s += sS[i][el];
+    for (int i = 1; i < 32; ++i) s += sS[i][el];
     const int n = e / Kout, k = e - n * Kout;
     if (k < K) dw[(size_t)n * K + k] = s;
     else if (db) db[n] = s;
@@ -600,25 +841,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
 }
 
 // partial[P][2][C] -> dbeta = sum gh, dgamma = sum gh*xh, c1 = dbeta/count, c2 = dgamma/count
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int P, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int P, int C,
                                                               double count, float *__restrict__ dgamma,
                                                               float *__restrict__ dbeta, float *__restrict__ c1,
                                                               float *__restrict__ c2)
 {
-    __shared__ double sS[8][32], sQ[8][32];
+    __shared__ double sS[32][33], sQ[32][33];
     const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int i = py; i < P; i += 8) {
-            s += (double)partial[((size_t)i * 2 + 0) * C + c];
-            q += (double)partial[((size_t)i * 2 + 1) * C + c];
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        int i = py;
+        for (; i + 32 < P; i += 64) {
+            s0 += partial[((size_t)i * 2 + 0) * C + c];
+            q0 += partial[((size_t)i * 2 + 1) * C + c];
+            s1 += partial[((size_t)(i + 32) * 2 + 0) * C + c];
+            q1 += partial[((size_t)(i + 32) * 2 + 1) * C + c];
         }
+        if (i < P) {
+            s0 += partial[((size_t)i * 2 + 0) * C + c];
+            q0 += partial[((size_t)i * 2 + 1) * C + c];
+        }
+        s = (double)s0 + (double)s1;
+        q = (double)q0 + (double)q1;
+    }
     sS[py][cl] = s;
     sQ[py][cl] = q;
     __syncthreads();
     if (py != 0 || c >= C) return;
-    for (int i = 1; i < 8; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
+    for (int i = 1; i < 32; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
     c1[c] = (float)(s / count);
@@ -633,9 +885,19 @@ inline unsigned grid_for(long long total, int threads)
 }
 
 template <int BN>
-int launch_gemm(const GemmArgs &a, int pro, bool vec4, int gx, hipStream_t stream)
+int launch_gemm(const GemmArgs &a, int pro, bool vec4, bool pipe, int gx, hipStream_t stream)
 {
     dim3 grid((unsigned)gx, (unsigned)((a.N + BN - 1) / BN));
+    if (pipe) {
+        int pool_shift = -1;
+        if (a.argk && (a.pool_k & (a.pool_k - 1)) == 0) { pool_shift = 0; while ((1 << pool_shift) < a.pool_k) ++pool_shift; }
+#define PN2_PIPE(P, W) hipLaunchKernelGGL((mlp_gemm_pipe_kernel<BN, P, W>), grid, dim3(MLP_THREADS), 0, stream, a, pool_shift)
+        if (pro == PRO_NONE) { if (a.wt) PN2_PIPE(PRO_NONE, true); else PN2_PIPE(PRO_NONE, false); }
+        else if (pro == PRO_BN_RELU) { if (a.wt) PN2_PIPE(PRO_BN_RELU, true); else PN2_PIPE(PRO_BN_RELU, false); }
+        else { if (a.wt) PN2_PIPE(PRO_BN_BWD, true); else PN2_PIPE(PRO_BN_BWD, false); }
+#undef PN2_PIPE
+        return PN2_LAUNCH_RC();
+    }
 #define PN2_GEMM(P, V) hipLaunchKernelGGL((mlp_gemm_kernel<BN, P, V>), grid, dim3(MLP_THREADS), 0, stream, a)
     if (pro == PRO_NONE) { if (vec4) PN2_GEMM(PRO_NONE, true); else PN2_GEMM(PRO_NONE, false); }
     else if (pro == PRO_BN_RELU) { if (vec4) PN2_GEMM(PRO_BN_RELU, true); else PN2_GEMM(PRO_BN_RELU, false); }
@@ -691,9 +953,12 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
     if (prologue == PRO_BN_BWD) vec4 = vec4 && aligned16(mean) && aligned16(invstd) && aligned16(c1) && aligned16(c2);
     const int gx = pn2_mlp_gemm_max_partials(M);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (N <= 32) return launch_gemm<32>(a, prologue, vec4, gx, stream);
-    if (N <= 64) return launch_gemm<64>(a, prologue, vec4, gx, stream);
-    return launch_gemm<128>(a, prologue, vec4, gx, stream);
+    // the pipelined kernel also stages the weight tile with float4 loads
+    bool pipe = vec4 && (ldw % 4 == 0) && aligned16(w) && (w_is_kn ? (N % 4 == 0) : true) && pn2::tune_get("mlp_pipe", 1);
+    if (prologue == PRO_BN_BWD && argk) pipe = pipe && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
+    if (N <= 32) return launch_gemm<32>(a, prologue, vec4, pipe, gx, stream);
+    if (N <= 64) return launch_gemm<64>(a, prologue, vec4, pipe, gx, stream);
+    return launch_gemm<128>(a, prologue, vec4, pipe, gx, stream);
 }
 
 PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma,
@@ -705,7 +970,7 @@ PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count,
     PN2_REQUIRE_PTR(scale);
     PN2_REQUIRE_PTR(shift);
     if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_), partial,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_), partial,
                        P, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
                        invstd_out);
     return PN2_LAUNCH_RC();
@@ -794,7 +1059,7 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK) return rc;
     const int total = N * (K + 1);
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, partial, P, N, K, dw, db);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(1024), 0, stream, partial, P, N, K, dw, db);
     return PN2_LAUNCH_RC();
 }
 
@@ -829,7 +1094,7 @@ PN2_EXPORT int pn2_bn_bwd_finalize(const float *partial, int P, int C, double co
     PN2_REQUIRE_PTR(c1);
     PN2_REQUIRE_PTR(c2);
     if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_),
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_),
                        partial, P, C, count, dgamma, dbeta, c1, c2);
     return PN2_LAUNCH_RC();
 }

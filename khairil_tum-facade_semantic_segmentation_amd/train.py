@@ -10,24 +10,32 @@ import torch.distributed as dist
 
 
 class FlatGradients:
-    """All parameter gradients of `module` as views into one contiguous fp32 buffer, so the
-    data-parallel exchange is a single collective (3.88 MB for pointnet2_sem_seg)."""
+    """Data-parallel gradient exchange as ONE collective: after backward the per-parameter
+    gradients are packed into a contiguous fp32 buffer (one concat kernel, 3.88 MB for
+    pointnet2_sem_seg), all-reduced, and the parameters' .grad become views of that buffer.
+    With a single process nothing is packed or copied at all."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
-        dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
-        self.buffer = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.buffer = None
+
+    def zero(self):
+        # None, not zeros: autograd then assigns each gradient instead of launching an add per parameter
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        self.buffer = torch.cat([g.reshape(-1) for g in grads])
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.buffer[off:off + n].view_as(p)   # autograd accumulates in place into this view
+            p.grad = self.buffer[off:off + n].view_as(p)
             off += n
-
-    def zero(self):
-        self.buffer.zero_()
+        return self.buffer
 
     def all_reduce_mean(self, group=None):
         """Sum over ranks, then divide by world size.  No-op for a single process."""
@@ -36,8 +44,9 @@ class FlatGradients:
         world = dist.get_world_size(group)
         if world == 1:
             return
-        dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=group)
-        self.buffer.div_(world)
+        flat = self.pack()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
 
 
 class SemSegTrainer:

@@ -1,0 +1,66 @@
+"""world_size-2 gloo test (CPU) of the data-parallel gradient exchange used by bench.py / the
+trainer for N > 1 GPUs: one all-reduce of the packed gradient buffer, replicas stay identical."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khairil_tum_facade_semantic_segmentation_amd.train import FlatGradients
+    torch.manual_seed(0)                                   # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    fg = FlatGradients(net)
+    opt = torch.optim.Adam(fg.params, lr=1e-2)
+    xs = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 6) / 10.0
+    x = xs[rank::world]                                    # each rank its own shard of the global batch
+    fg.zero()
+    loss = net(x).pow(2).sum()
+    loss.backward()
+    fg.all_reduce_mean()
+    flat = fg.buffer.clone()
+    opt.step()
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    # single-process reference over the full batch: mean of per-rank sums == sum / world
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    (ref(xs).pow(2).sum() / world).backward()
+    ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    ok = torch.allclose(flat, ref_flat, rtol=1e-5, atol=1e-6) and all(torch.equal(gathered[0], g) for g in gathered)
+    ok = ok and all(p.grad.data_ptr() >= fg.buffer.data_ptr() for p in fg.params)      # grads are views of the buffer
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_world2():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_single_process_is_a_noop():
+    from khairil_tum_facade_semantic_segmentation_amd.train import FlatGradients
+    net = torch.nn.Linear(3, 2)
+    fg = FlatGradients(net)
+    fg.zero()
+    assert all(p.grad is None for p in fg.params)
+    net(torch.ones(1, 3)).sum().backward()
+    fg.all_reduce_mean()                                    # no process group: nothing to do
+    assert fg.buffer is None and fg.numel == 8
