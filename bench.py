@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--kind", default="cube", choices=("cube", "facade"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="compute each batch's FPS/ball-query/3-NN pyramid inside its own step instead of one step ahead on a side stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +103,8 @@ def main():
     model = M.get_model(NUM_CLASSES, CHANNELS - 6)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     model = model.to(dev)
-    trainer = SemSegTrainer(model, class_weight=torch.ones(NUM_CLASSES, device=dev))
+    trainer = SemSegTrainer(model, class_weight=torch.ones(NUM_CLASSES, device=dev), graphs=not args.no_graphs,
+                            prefetch_geometry=not args.no_prefetch)
     trainer.broadcast_parameters()
 
     def barrier():
@@ -108,7 +112,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 5 if not args.no_graphs else 0)):   # >= 3 eager + capture + 1 replay before timing
         trainer.step(x, y)
     barrier()
     t0 = time.perf_counter()

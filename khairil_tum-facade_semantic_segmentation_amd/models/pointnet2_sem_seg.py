@@ -7,6 +7,7 @@ between levels so no tensor is re-laid-out on the way through the network."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction
 
 # (npoint, radius, nsample, mlp) per set-abstraction level; reference :9-12
@@ -31,18 +32,38 @@ class get_model(nn.Module):
         self.drop1 = nn.Dropout(0.5)
         self.conv2 = nn.Conv1d(128, num_classes, 1)
 
-    def forward(self, xyz):
+    def compute_geometry(self, xyz):
+        """Everything in the forward pass that depends on the input coordinates only: the FPS /
+        ball-query pyramid of the four SA levels and the 3-NN tables of the four FP levels
+        (SURVEY.md 3.3).  Returns a flat list of tensors that forward(geometry=...) consumes; it
+        can be computed ahead of time (another stream, one batch early) because no learned
+        quantity feeds it."""
+        cur = xyz.permute(0, 2, 1)[:, :, :3].contiguous()
+        levels = [cur]
+        out = []
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            new_xyz, idx = sa.geometry(levels[-1])
+            out += [new_xyz, idx]
+            levels.append(new_xyz)
+        for lvl in (3, 2, 1, 0):
+            idx3, w3 = ops.three_nn(levels[lvl], levels[lvl + 1])
+            out += [idx3, w3]
+        return out
+
+    def forward(self, xyz, geometry=None):
         """xyz [B, 3+3+extra, N] -> (log_softmax [B,N,classes], l4_points [B,512,16])."""
         pts = xyz.permute(0, 2, 1).contiguous()          # [B,N,C]
         geo = [pts[:, :, :3].contiguous()]
         feat = [pts]
-        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
-            g, f = sa.forward_cl(geo[-1], feat[-1])
+        for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
+            pre = None if geometry is None else (geometry[2 * i], geometry[2 * i + 1])
+            g, f = sa.forward_cl(geo[-1], feat[-1], geometry=pre)
             geo.append(g)
             feat.append(f)
         up = feat[4]
-        for lvl, fp in zip((3, 2, 1, 0), (self.fp4, self.fp3, self.fp2, self.fp1)):
-            up = fp.forward_cl(geo[lvl], geo[lvl + 1], feat[lvl] if lvl else None, up)   # :31-34
+        for j, (lvl, fp) in enumerate(zip((3, 2, 1, 0), (self.fp4, self.fp3, self.fp2, self.fp1))):
+            pre = None if geometry is None else (geometry[8 + 2 * j], geometry[9 + 2 * j])
+            up = fp.forward_cl(geo[lvl], geo[lvl + 1], feat[lvl] if lvl else None, up, nn=pre)   # :31-34
         h = up.permute(0, 2, 1)
         h = self.drop1(F.relu(self.bn1(self.conv1(h))))  # :36
         h = F.log_softmax(self.conv2(h), dim=1)          # :37-38

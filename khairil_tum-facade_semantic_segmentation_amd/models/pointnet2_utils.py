@@ -136,10 +136,22 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
             self.mlp_convs.append(nn.Conv2d(ci, co, 1))
             self.mlp_bns.append(nn.BatchNorm2d(co))
 
-    def forward_cl(self, xyz, points, start=None):
-        """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C']."""
+    def geometry(self, xyz, start=None):
+        """The part of the level that depends on xyz only: FPS centroids and
+        ball-query indices.  xyz [B,N,3] -> (new_xyz [B,S,3], idx [B,S,K])."""
+        if start is None:
+            start = _next_start(xyz.device)
+        _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, self.npoint, start)
+        return new_xyz, ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+
+    def forward_cl(self, xyz, points, start=None, geometry=None):
+        """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C'].
+        `geometry` = a precomputed (new_xyz, idx) pair from geometry()."""
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz, points)
+        elif geometry is not None:
+            new_xyz, idx = geometry
+            grouped = ops.group_points(xyz, new_xyz, points, idx)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)
         B, S, K, C = grouped.shape
@@ -192,14 +204,15 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
             self.mlp_convs.append(nn.Conv1d(ci, co, 1))
             self.mlp_bns.append(nn.BatchNorm1d(co))
 
-    def forward_cl(self, xyz1, xyz2, points1, points2):
-        """Channel-last: xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,D1]|None, points2 [B,S,D2] -> [B,N,C']."""
+    def forward_cl(self, xyz1, xyz2, points1, points2, nn=None):
+        """Channel-last: xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,D1]|None, points2 [B,S,D2] -> [B,N,C'].
+        `nn` = a precomputed (idx3, weight3) pair from ops.three_nn(xyz1, xyz2)."""
         B, N, _ = xyz1.shape
         S = xyz2.shape[1]
         if S == 1:                                      # :293-294
             interpolated = points2.expand(B, N, points2.shape[-1])
         else:
-            idx3, w3 = ops.three_nn(xyz1, xyz2)         # :296-302
+            idx3, w3 = nn if nn is not None else ops.three_nn(xyz1, xyz2)   # :296-302
             interpolated = ops.three_interpolate(points2, idx3, w3)   # :303
         D2 = interpolated.shape[-1]
         if points1 is None:                             # :305-309 (the concat is never materialised)

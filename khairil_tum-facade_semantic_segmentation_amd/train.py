@@ -50,14 +50,35 @@ class FlatGradients:
 
 
 class SemSegTrainer:
-    def __init__(self, model, lr=1e-3, weight_decay=1e-4, class_weight=None, group=None):
+    """graphs=True (HIP device only): the step is captured into hipGraphs after a few eager
+    warm-up steps and replayed -- one graph for zero_grad+forward+loss+backward(+gradient
+    packing), the all-reduce issued eagerly between (world > 1), one graph for Adam; with a single
+    process everything is one graph.  ~250 kernel launches per step otherwise keep the host as
+    busy as the GPU."""
+
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, class_weight=None, group=None, graphs=False,
+                 graph_warmup=3, prefetch_geometry=False):
         self.model = model
         self.group = group
         self.grads = FlatGradients(model)
         self.class_weight = class_weight
-        fused = next(model.parameters()).is_cuda
+        on_gpu = next(model.parameters()).is_cuda
+        self.graphs = bool(graphs) and on_gpu
         self.optimizer = torch.optim.Adam(self.grads.params, lr=lr, betas=(0.9, 0.999), eps=1e-8,
-                                          weight_decay=weight_decay, fused=fused)
+                                          weight_decay=weight_decay, fused=on_gpu, capturable=self.graphs)
+        # prefetch_geometry: the FPS / ball-query / 3-NN pyramid of the NEXT batch (a function of
+        # its coordinates only) is computed on a side stream while this batch's MLP work runs:
+        # FPS is a latency-bound chain that occupies 16 of 256 CUs.
+        self.prefetch = bool(prefetch_geometry) and on_gpu and hasattr(model, "compute_geometry")
+        self._side = torch.cuda.Stream() if self.prefetch else None
+        self._geo_next = None            # pyramid computed for the coming step
+        self._geo_event = None
+        self._geo_cur = None             # (graph mode) static buffers the forward reads
+        self._static_next_x = None
+        self._graph_warmup = graph_warmup
+        self._eager_steps = 0
+        self._g_fwd_bwd = self._g_opt = None
+        self._static_x = self._static_y = self._static_loss = None
 
     def broadcast_parameters(self, src=0):
         """Replicas start identical: rank `src`'s parameters and buffers go to every rank."""
@@ -66,15 +87,107 @@ class SemSegTrainer:
         for t in list(self.model.parameters()) + list(self.model.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
 
-    def step(self, blocks_cf, target):
-        """blocks_cf [B,C,N] (channel-first like the reference loop, localfunctions.py:209),
-        target [B,N] int64.  Returns the (rank-local) loss tensor, no host sync."""
-        self.model.train()
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def _launch_prefetch(self, next_blocks_cf):
+        """Enqueue the geometry pyramid of `next_blocks_cf` on the side stream."""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            with torch.no_grad():
+                geo = self.model.compute_geometry(next_blocks_cf)
+        return geo
+
+    def _forward_backward(self, blocks_cf, target, geometry=None):
         self.grads.zero()
-        pred, _ = self.model(blocks_cf)
+        pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
         loss = torch.nn.functional.nll_loss(pred.reshape(-1, pred.shape[-1]), target.reshape(-1),
                                             weight=self.class_weight)
         loss.backward()
+        return loss.detach()
+
+    def _eager_step(self, blocks_cf, target, next_blocks_cf=None):
+        geo = None
+        if self.prefetch:
+            main = torch.cuda.current_stream()
+            if self._geo_next is None:                   # first step: nothing was prefetched
+                self._geo_next = self._launch_prefetch(blocks_cf)
+            main.wait_stream(self._side)
+            geo, self._geo_next = self._geo_next, None
+            nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
+            self._geo_next = self._launch_prefetch(nxt)  # overlaps with everything below
+            for t in self._geo_next:
+                t.record_stream(self._side)
+        loss = self._forward_backward(blocks_cf, target, geo)
         self.grads.all_reduce_mean(self.group)
         self.optimizer.step()
-        return loss.detach()
+        return loss
+
+    def _capture(self, blocks_cf, target):
+        world = self._world()
+        self._static_x = blocks_cf.clone()
+        self._static_y = target.clone()
+        if self.prefetch:
+            # static pyramid buffers: `cur` is read by the forward, `next` is (re)written by the
+            # side branch of every replay and copied into `cur` at the start of the following one
+            self._static_next_x = blocks_cf.clone()
+            torch.cuda.current_stream().wait_stream(self._side)
+            with torch.no_grad():
+                self._geo_cur = [t.clone() for t in self.model.compute_geometry(self._static_x)]
+            self._geo_next = [t.clone() for t in self._geo_cur]
+            torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self._g_fwd_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fwd_bwd, pool=pool):
+            geo = None
+            if self.prefetch:
+                for cur, nxt in zip(self._geo_cur, self._geo_next):
+                    cur.copy_(nxt)
+                new_geo = self._launch_prefetch(self._static_next_x)      # fork: side branch of the graph
+                with torch.cuda.stream(self._side):
+                    for nxt, new in zip(self._geo_next, new_geo):
+                        nxt.copy_(new)
+                geo = self._geo_cur
+            self._static_loss = self._forward_backward(self._static_x, self._static_y, geo)
+            if self.prefetch:
+                torch.cuda.current_stream().wait_stream(self._side)       # join
+            if world > 1:
+                self.grads.pack()                       # .grad become views of one flat buffer
+            else:
+                self.optimizer.step()
+        if world > 1:
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt, pool=pool):
+                self.optimizer.step()
+
+    def step(self, blocks_cf, target, next_blocks_cf=None):
+        """blocks_cf [B,C,N] (channel-first like the reference loop, localfunctions.py:209),
+        target [B,N] int64; next_blocks_cf (optional, with prefetch_geometry) is the batch the
+        NEXT call will train on (default: the same batch again).  Returns the (rank-local) loss
+        tensor, no host sync."""
+        self.model.train()
+        if not self.graphs:
+            return self._eager_step(blocks_cf, target, next_blocks_cf)
+        if self._g_fwd_bwd is None:
+            if self._eager_steps < self._graph_warmup:  # allocator / MIOpen / lazy inits settle first
+                self._eager_steps += 1
+                return self._eager_step(blocks_cf, target, next_blocks_cf)
+            torch.cuda.synchronize()
+            self._geo_next = None
+            self._capture(blocks_cf, target)
+        if blocks_cf.data_ptr() != self._static_x.data_ptr():
+            self._static_x.copy_(blocks_cf)
+        if target.data_ptr() != self._static_y.data_ptr():
+            self._static_y.copy_(target)
+        if self.prefetch:
+            self._static_next_x.copy_(blocks_cf if next_blocks_cf is None else next_blocks_cf)
+        self._g_fwd_bwd.replay()
+        if self._g_opt is not None:
+            world = self._world()
+            dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)
+            self.grads.buffer.div_(world)
+            self._g_opt.replay()
+        return self._static_loss
