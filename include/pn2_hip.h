@@ -62,10 +62,12 @@ int pn2_square_distance(const float *src, const float *dst, int B, int N, int M,
  * idx[B,S,nsample] int64; grouped (nullable) [B,S,nsample,3+D] = [xyz[idx]-new_xyz, points[idx]];
  * points nullable (then D must be 0).  A centroid with no point inside the radius
  * (reference: IndexError at :59) gets idx = N, a zero grouped row block and err_count += 1.
+ * ldg = row pitch of grouped in floats (0 = dense 3+D; a larger pitch zero-fills columns [3+D, ldg),
+ * used to keep the MLP's rows 16-byte aligned when 3+D is not a multiple of 4).
  * Limits: 1 <= nsample <= 64. */
 int pn2_ball_query_group(double radius, int nsample, const float *xyz, const float *new_xyz,
                          const float *points, int B, int N, int S, int D, int64_t *idx, float *grouped,
-                         int32_t *err_count, pn2_stream_t stream);
+                         int ldg, int32_t *err_count, pn2_stream_t stream);
 
 /* index_points(points, idx) -> out[B,M,C]                models/pointnet2_utils.py:43-60
  * idx is [B,M] (any trailing idx dims flattened into M).  Out-of-range index: zero row,
@@ -82,7 +84,7 @@ int pn2_index_points_backward(const float *grad_out, const int64_t *idx, int B, 
 
 /* grouping half of sample_and_group for a given idx      models/pointnet2_utils.py:127-132 */
 int pn2_group_points(const float *xyz, const float *new_xyz, const float *points, const int64_t *idx,
-                     int B, int N, int S, int K, int D, float *grouped, int32_t *err_count,
+                     int B, int N, int S, int K, int D, float *grouped, int ldg, int32_t *err_count,
                      pn2_stream_t stream);
 
 /* three nearest neighbours + inverse-distance weights of PointNetFeaturePropagation

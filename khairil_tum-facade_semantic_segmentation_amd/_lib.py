@@ -16,10 +16,10 @@ SIGNATURES = {
     "pn2_error_string": [_ci],
     "pn2_farthest_point_sample": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_square_distance": [_vp, _vp, _ci, _ci, _ci, _vp, _vp],
-    "pn2_ball_query_group": [_cd, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "pn2_ball_query_group": [_cd, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp],
     "pn2_index_points": [_vp, _vp, _ci, _ci, _ci, _cl, _vp, _vp, _vp],
     "pn2_index_points_backward": [_vp, _vp, _ci, _ci, _ci, _cl, _ci, _ci, _vp, _vp],
-    "pn2_group_points": [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
+    "pn2_group_points": [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp],
     "pn2_three_nn": [_vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
     "pn2_three_interpolate_backward": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],

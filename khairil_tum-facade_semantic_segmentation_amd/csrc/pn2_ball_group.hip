@@ -59,11 +59,30 @@ __device__ __forceinline__ v2f pk_add_phi(v2f t, v2f p)
     return r;
 }
 
+// Two independent chains (centroid pairs A and B) of the five packed ops, interleaved:
+//   t = p.x*cx ; t = p.y*cy + t ; t = p.z*cz + t ; t = -2*t + |c|^2 ; t = t + |p|^2
+__device__ __forceinline__ void pk_dist_x2(v2f &ta, v2f &tb, v2f pxy, v2f pzw, v2f ax, v2f ay, v2f az, v2f an,
+                                           v2f bx, v2f by, v2f bz, v2f bn, v2f m2)
+{
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %2, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %10, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %0, %12, %7\n\t"
+        "v_pk_fma_f32 %1, %1, %12, %11\n\t"
+        "v_pk_add_f32 %0, %0, %3 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %1, %1, %3 op_sel:[0,1] op_sel_hi:[1,1]"
+        : "=&v"(ta), "=&v"(tb)
+        : "v"(pxy), "v"(pzw), "v"(ax), "v"(ay), "v"(az), "v"(an), "v"(bx), "v"(by), "v"(bz), "v"(bn), "v"(m2));
+}
+
 // THREADS per workgroup, CPW (even) centroids per wave.
 template <int THREADS, int CPW>
 __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
-    int B, int N, int S, int K, int D, float r2, int tiles_per_block, unsigned cg_magic,
+    int B, int N, int S, int K, int D, int ldg, float r2, int tiles_per_block, unsigned cg_magic,
     int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
 {
     static_assert(CPW % 2 == 0, "centroids are processed in packed pairs");
@@ -153,19 +172,20 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
             bool hit[CPW];
             unsigned long long any = 0;
             // src = new_xyz (centroid), dst = xyz (point): pointnet2_utils.py:101, 37-39.
-            // Stage-wise over the PAIRS independent chains so dependent packed ops never issue
-            // back to back.
+            // The five packed ops of two centroid pairs are interleaved inside ONE asm statement:
+            // dependent ops never issue back to back and hipcc adds no pad between statements.
             v2f t[PAIRS];
 #pragma unroll
-            for (int q = 0; q < PAIRS; ++q) t[q] = pk_mul_plo(pxy, cx2[q]);          // a0*b0
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) t[q] = pk_fma_phi(pxy, cy2[q], t[q]);    // fma(a1,b1,.)
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) t[q] = pk_fma_plo(pzw, cz2[q], t[q]);    // fma(a2,b2,.) = dot
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) t[q] = pk_fma(t[q], minus2, cn2[q]);     // (-2*dot) + |centroid|^2, one rounding
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) t[q] = pk_add_phi(t[q], pzw);            // + |point|^2
+            for (int q = 0; q + 1 < PAIRS; q += 2) pk_dist_x2(t[q], t[q + 1], pxy, pzw, cx2[q], cy2[q], cz2[q], cn2[q],
+                                                              cx2[q + 1], cy2[q + 1], cz2[q + 1], cn2[q + 1], minus2);
+            if (PAIRS & 1) {
+                const int q = PAIRS - 1;
+                t[q] = pk_mul_plo(pxy, cx2[q]);                  // a0*b0
+                t[q] = pk_fma_phi(pxy, cy2[q], t[q]);            // fma(a1,b1,.)
+                t[q] = pk_fma_plo(pzw, cz2[q], t[q]);            // fma(a2,b2,.) = dot
+                t[q] = pk_fma(t[q], minus2, cn2[q]);             // (-2*dot) + |centroid|^2, one rounding
+                t[q] = pk_add_phi(t[q], pzw);                    // + |point|^2
+            }
 #pragma unroll
             for (int q = 0; q < PAIRS; ++q) {
                 hit[2 * q] = !(t[q].x > r2);                     // :102  (hit = not masked out)
@@ -192,8 +212,8 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     }
 
     // ---- pad + idx (int64) -------------------------------------------------------------
-    const int Cg = 3 + D;
-    const int row_elems = K * Cg;
+    const int Cg = 3 + D;                    // logical row width; rows are stored with pitch ldg >= Cg,
+    const int row_elems = K * ldg;           // pad columns [Cg, ldg) zero-filled
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int s = s0 + c;
@@ -232,20 +252,20 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
                 const int k = e / 3, col = e - k * 3;
                 const int j = lst[k];
                 const float cc = col == 0 ? ctr[0] : (col == 1 ? ctr[1] : ctr[2]);
-                g[k * Cg + col] = j >= 0 ? bx[(size_t)j * 3 + col] - cc : 0.0f;   // :128
+                g[k * ldg + col] = j >= 0 ? bx[(size_t)j * 3 + col] - cc : 0.0f;   // :128
             }
 #pragma unroll 4
             for (int k = 0; k < K; ++k) {
                 const int j = __builtin_amdgcn_readfirstlane(lst[k]);
                 const float *src = bp + (size_t)max(j, 0) * D;
-                float *dst = g + (size_t)k * Cg + 3;
-                for (int col = lane; col < D; col += PN2_WAVE)
-                    dst[col] = j >= 0 ? src[col] : 0.0f;                        // :131-132
+                float *dst = g + (size_t)k * ldg + 3;
+                for (int col = lane; col < ldg - 3; col += PN2_WAVE)
+                    dst[col] = (j >= 0 && col < D) ? src[col] : 0.0f;           // :131-132 (+ zero pad)
             }
         }
         return;
     }
-    if ((Cg & 3) == 0 && ((reinterpret_cast<uintptr_t>(grouped) & 15) == 0)) {
+    if (ldg == Cg && (Cg & 3) == 0 && ((reinterpret_cast<uintptr_t>(grouped) & 15) == 0)) {
         // Narrow rows whose width is a multiple of 4 floats (SA1: 3+9 = 12): one float4 of the
         // output per lane and step; quad 0 of a row is [xyz - centroid, feat0], quad p > 0 is
         // feats[4p-3 .. 4p] (one dword-aligned 16-B load).  16-B aligned coalesced stores.
@@ -297,10 +317,10 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
                 const int f = f0 + u * PN2_WAVE + lane;
                 v[u] = 0.0f;
                 if (f < row_elems) {
-                    const int k = (int)__umulhi((unsigned)f, cg_magic);          // f / Cg (exact: host checks the range)
-                    const int col = f - k * Cg;
+                    const int k = (int)__umulhi((unsigned)f, cg_magic);          // f / ldg (exact: host checks the range)
+                    const int col = f - k * ldg;
                     const int j = lst[k];
-                    if (j >= 0) {
+                    if (j >= 0 && col < Cg) {
                         if (col < 3) {
                             const float ctr = col == 0 ? ccx : (col == 1 ? ccy : ccz);
                             v[u] = bx[(size_t)j * 3 + col] - ctr;                // :128
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
 
 template <int THREADS, int CPW>
 int launch_ball_query_group(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
-                            int D, float r2, int64_t *idx, float *grouped, int32_t *err_count, hipStream_t stream)
+                            int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count, hipStream_t stream)
 {
     constexpr int WAVES = THREADS / PN2_WAVE;
     const int per_wg = WAVES * CPW;
@@ -330,9 +350,8 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
     const size_t lds = (size_t)tile_pts * sizeof(float4) + (size_t)WAVES * CPW * (K + PN2_WAVE) * sizeof(int);
     const long long nwg = (long long)B * tiles;
     if (nwg > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
-    const int Cg = 3 + D;
-    if ((long long)K * Cg + PN2_WAVE * BQ_UNROLL >= (1LL << 32) / Cg) return PN2_ERR_UNSUPPORTED;
-    const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cg) + 1u;   // umulhi(f, magic) == f / Cg for f*Cg < 2^32
+    if ((long long)K * ldg + PN2_WAVE * BQ_UNROLL >= (1LL << 32) / ldg) return PN2_ERR_UNSUPPORTED;
+    const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)ldg) + 1u;   // umulhi(f, magic) == f / ldg for f*ldg < 2^32
     auto kern = ball_query_group_kernel<THREADS, CPW>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -340,7 +359,7 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(THREADS), lds, stream, xyz, new_xyz, points, B, N, S, K, D,
-                       r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
+                       ldg, r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
     return PN2_LAUNCH_RC();
 }
 
@@ -348,7 +367,7 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
 
 PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz, const float *new_xyz,
                                     const float *points, int B, int N, int S, int D, int64_t *idx,
-                                    float *grouped, int32_t *err_count, pn2_stream_t stream_)
+                                    float *grouped, int ldg, int32_t *err_count, pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(xyz);
     PN2_REQUIRE_PTR(new_xyz);
@@ -356,6 +375,8 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
     if (B < 0 || N <= 0 || S <= 0 || D < 0 || nsample <= 0) return PN2_ERR_SHAPE;
     if (D > 0 && points == nullptr) return PN2_ERR_NULL;
     if (nsample > 64) return PN2_ERR_UNSUPPORTED;
+    if (ldg == 0) ldg = 3 + D;
+    if (ldg < 3 + D) return PN2_ERR_SHAPE;
     if (B == 0) return PN2_OK;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -367,11 +388,11 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
     // Few centroids with wide rows (deep levels): the gather is latency-bound inside the scan
     // waves, so the scan kernel writes idx only and a fully parallel elementwise kernel groups.
     if (grouped && total < 2048 && pn2::tune_get("bq_split", 1)) {
-        int rc = pn2_ball_query_group(radius, nsample, xyz, new_xyz, nullptr, B, N, S, 0, idx, nullptr, err_count, stream_);
+        int rc = pn2_ball_query_group(radius, nsample, xyz, new_xyz, nullptr, B, N, S, 0, idx, nullptr, 0, err_count, stream_);
         if (rc != PN2_OK) return rc;
-        return pn2_group_points(xyz, new_xyz, points, idx, B, N, S, nsample, D, grouped, nullptr, stream_);
+        return pn2_group_points(xyz, new_xyz, points, idx, B, N, S, nsample, D, grouped, ldg, nullptr, stream_);
     }
-#define PN2_BQ(T, C) return launch_ball_query_group<T, C>(xyz, new_xyz, points, B, N, S, nsample, D, r2, idx, grouped, err_count, stream)
+#define PN2_BQ(T, C) return launch_ball_query_group<T, C>(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped, err_count, stream)
     switch (cfg) {
         case 0: PN2_BQ(512, 8);
         case 1: PN2_BQ(256, 2);

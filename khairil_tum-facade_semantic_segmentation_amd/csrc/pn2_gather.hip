@@ -57,20 +57,21 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float *__restri
                                                            const float *__restrict__ new_xyz,
                                                            const float *__restrict__ points,
                                                            const int64_t *__restrict__ idx, int N, int S, int K,
-                                                           int D, unsigned cg_magic, float *__restrict__ grouped,
+                                                           int D, int ldg, unsigned cg_magic, float *__restrict__ grouped,
                                                            int32_t *err_count)
 {
-    const int Cg = 3 + D;
-    const int row_elems = K * Cg;
+    const int Cg = 3 + D;                              // logical width; stored pitch ldg >= Cg, pad zero-filled
+    const int row_elems = K * ldg;
     const int f = blockIdx.y * 256 + threadIdx.x;
     if (f >= row_elems) return;
     const unsigned bs = blockIdx.x;                    // b*S + s
     const unsigned b = bs / (unsigned)S;
     const int k = (int)__umulhi((unsigned)f, cg_magic);
-    const int c = f - k * Cg;
+    const int c = f - k * ldg;
     const int64_t j = idx[(size_t)bs * K + k];
     float v = 0.0f;
-    if (j >= 0 && j < N) {
+    if (c >= Cg) {
+    } else if (j >= 0 && j < N) {
         if (c < 3) v = xyz[((size_t)b * N + j) * 3 + c] - new_xyz[(size_t)bs * 3 + c];   // :128
         else v = points[((size_t)b * N + j) * D + (c - 3)];                              // :131-132
     } else if (c == 0 && err_count) atomicAdd(err_count, 1);
@@ -147,7 +148,7 @@ PN2_EXPORT int pn2_index_points_backward(const float *grad_out, const int64_t *i
 }
 
 PN2_EXPORT int pn2_group_points(const float *xyz, const float *new_xyz, const float *points, const int64_t *idx,
-                                int B, int N, int S, int K, int D, float *grouped, int32_t *err_count,
+                                int B, int N, int S, int K, int D, float *grouped, int ldg, int32_t *err_count,
                                 pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(xyz);
@@ -156,15 +157,17 @@ PN2_EXPORT int pn2_group_points(const float *xyz, const float *new_xyz, const fl
     PN2_REQUIRE_PTR(grouped);
     if (B < 0 || N <= 0 || S <= 0 || K <= 0 || D < 0) return PN2_ERR_SHAPE;
     if (D > 0 && points == nullptr) return PN2_ERR_NULL;
+    if (ldg == 0) ldg = 3 + D;
+    if (ldg < 3 + D) return PN2_ERR_SHAPE;
     if (B == 0) return PN2_OK;
-    const int Cg = 3 + D;
+    const int Cg = ldg;
     const long long row_elems = (long long)K * Cg;
     const long long rows = (long long)B * S;
     const long long ny = (row_elems + 255) / 256;
     if (rows > 0x7fffffffLL || ny > 65535 || row_elems + 256 >= (1LL << 32) / Cg) return PN2_ERR_UNSUPPORTED;
     const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cg) + 1u;     // umulhi(f, magic) == f / Cg
     hipLaunchKernelGGL(group_points_kernel, dim3((unsigned)rows, (unsigned)ny), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), xyz, new_xyz, points, idx, N, S, K, D, magic, grouped,
+                       static_cast<hipStream_t>(stream_), xyz, new_xyz, points, idx, N, S, K, D, ldg, magic, grouped,
                        err_count);
     return PN2_LAUNCH_RC();
 }

@@ -155,7 +155,7 @@ class _MLPStack(torch.autograd.Function):
                                     _ptr(a2), 0 if a2 is None else a2.stride(0), ak2, _ptr(asc), _ptr(ash), M, Co, _ptr(wpart),
                                     _ptr(dw), _ptr(db), _stream(dev))
                 _lib.check(rc, "pn2_mlp_dw")
-                grads[4 * l], grads[4 * l + 1] = dw.view_as(w), db
+                grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db
                 # dX (= gradient w.r.t. the activation below), masked + reduced for the layer below
                 if l > 0:
                     zp = zs[l - 1]
@@ -191,8 +191,19 @@ def mlp_stack(x1, x2, convs, bns, pool_k=0):
         if x2.stride(-1) != 1:
             x2 = x2.contiguous()
     params = []
-    for conv, bn in zip(convs, bns):
+    for l, (conv, bn) in enumerate(zip(convs, bns)):
         if conv.bias is None or bn.weight is None or bn.bias is None:
             raise NotImplementedError("mlp_stack expects conv bias and affine BatchNorm (as the reference builds them)")
-        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+        w = conv.weight
+        if l == 0:
+            # rows may carry zero pad columns (16-byte aligned rows): pad the weight to match; autograd
+            # slices the gradient back (tiny tensors, two extra kernels per stack)
+            cin = w.shape[1]
+            kin = x1.shape[1] + (0 if x2 is None else x2.shape[1])
+            if kin < cin or (kin > cin and x2 is not None):
+                raise ValueError("input rows have %d columns, first conv expects %d" % (kin, cin))
+            w = w.reshape(w.shape[0], cin)
+            if kin > cin:
+                w = torch.nn.functional.pad(w, (0, kin - cin))
+        params += [w, conv.bias, bn.weight, bn.bias]
     return _MLPStack.apply(list(bns), pool_k, x1, x2, *params)

@@ -73,12 +73,13 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return ops.query_ball_point(radius, nsample, xyz, new_xyz)
 
 
-def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start=None):
-    """-> new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D]  (:110-138)."""
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start=None, pad_to=1):
+    """-> new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D]  (:110-138).  pad_to > 1 (internal)
+    rounds the last dimension up with zero columns."""
     if start is None:
         start = _next_start(xyz.device)
     fps_idx, new_xyz = ops.farthest_point_sample_with_xyz(xyz, npoint, start)
-    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points)
+    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to)
     if returnfps:
         grouped_xyz = ops.index_points(xyz, idx)
         return new_xyz, new_points, grouped_xyz, fps_idx
@@ -101,10 +102,11 @@ _TORCH_MLP = os.environ.get("PN2_TORCH_MLP", "0") == "1"
 
 
 def _mlp(x1, x2, convs, bns, pool_k=0):
-    """[rows, K1] | [rows, K2] -> [rows(/pool_k), Cout] through the fused HIP stack."""
+    """[rows, K1] | [rows, K2] -> [rows(/pool_k), Cout] through the fused HIP stack.  x1 may carry
+    zero pad columns beyond the first conv's input width (see ops.ball_query_group pad_to)."""
     if _TORCH_MLP:
         x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
-        y = _pointwise_mlp(x, convs, bns)
+        y = _pointwise_mlp(x[:, :convs[0].weight.shape[1]], convs, bns)
         return y.reshape(-1, pool_k, y.shape[-1]).max(dim=1)[0] if pool_k else y
     return mlp.mlp_stack(x1, x2, convs, bns, pool_k)
 
@@ -151,9 +153,10 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
             new_xyz, grouped = sample_and_group_all(xyz, points)
         elif geometry is not None:
             new_xyz, idx = geometry
-            grouped = ops.group_points(xyz, new_xyz, points, idx)
+            grouped = ops.group_points(xyz, new_xyz, points, idx, pad_to=4)
         else:
-            new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)
+            new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start,
+                                                pad_to=4)
         B, S, K, C = grouped.shape
         y = _mlp(grouped.reshape(B * S * K, C), None, self.mlp_convs, self.mlp_bns, pool_k=K)   # :196-200
         return new_xyz, y.reshape(B, S, -1)

@@ -121,17 +121,22 @@ def square_distance(src, dst):
 
 
 # ---------------------------------------------------------------------------------- grouping
-def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped):
+def _padded(width, pad_to):
+    return (width + pad_to - 1) // pad_to * pad_to
+
+
+def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, pad_to=1):
     dev = _dev(xyz, new_xyz, points)
     lib = _lib.load()
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     D = 0 if points is None else points.shape[2]
+    ldg = _padded(3 + D, pad_to)
     idx = torch.empty((B, S, nsample), dtype=torch.int64, device=dev)
-    grouped = torch.empty((B, S, nsample, 3 + D), dtype=torch.float32, device=dev) if want_grouped else None
+    grouped = torch.empty((B, S, nsample, ldg), dtype=torch.float32, device=dev) if want_grouped else None
     with torch.cuda.device(dev):
         rc = lib.pn2_ball_query_group(float(radius), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(points), B, N, S,
-                                      D, _ptr(idx), _ptr(grouped), _ptr(_err_word(dev)), _stream(dev))
+                                      D, _ptr(idx), _ptr(grouped), ldg, _ptr(_err_word(dev)), _stream(dev))
     _lib.check(rc, "pn2_ball_query_group")
     _after_fault_op(dev, "query_ball_point")
     return idx, grouped
@@ -148,8 +153,8 @@ class _BallQueryGroup(torch.autograd.Function):
     (SURVEY.md 3.3)."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, radius, nsample):
-        idx, grouped = _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, True)
+    def forward(ctx, xyz, new_xyz, points, radius, nsample, pad_to):
+        idx, grouped = _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, True, pad_to)
         ctx.save_for_backward(idx)
         ctx.shape = (xyz.shape[0], xyz.shape[1], 0 if points is None else points.shape[2])
         ctx.mark_non_differentiable(idx)
@@ -160,16 +165,18 @@ class _BallQueryGroup(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, D = ctx.shape
         if D == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None, None
-        return None, None, index_points_backward(ggrouped, idx, N, D, col0=3), None, None
+            return None, None, None, None, None, None
+        return None, None, index_points_backward(ggrouped, idx, N, D, col0=3), None, None, None
 
 
-def ball_query_group(radius, nsample, xyz, new_xyz, points):
-    """Fused query_ball_point + grouping: (idx [B,S,K] int64, grouped [B,S,K,3+D])."""
+def ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to=1):
+    """Fused query_ball_point + grouping: (idx [B,S,K] int64, grouped [B,S,K,3+D]).  pad_to = 4
+    rounds the row width up to a multiple of 4 floats (extra columns are zero) so that the MLP
+    kernels can use 16-byte loads on widths like 67 / 131 / 259."""
     xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
     if points is not None:
         points = points.to(torch.float32).contiguous()
-    return _BallQueryGroup.apply(xyz, new_xyz, points, radius, nsample)
+    return _BallQueryGroup.apply(xyz, new_xyz, points, radius, nsample, pad_to)
 
 
 def index_points_backward(grad_out, idx, N, D, col0=0):
@@ -220,15 +227,16 @@ def index_points(points, idx):
 
 class _GroupPoints(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, idx):
+    def forward(ctx, xyz, new_xyz, points, idx, pad_to):
         dev = _dev(xyz, new_xyz, points, idx)
         lib = _lib.load()
         B, N, _ = xyz.shape
         _, S, K = idx.shape
         D = 0 if points is None else points.shape[2]
-        out = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=dev)
+        ldg = _padded(3 + D, pad_to)
+        out = torch.empty((B, S, K, ldg), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.pn2_group_points(_ptr(xyz), _ptr(new_xyz), _ptr(points), _ptr(idx), B, N, S, K, D, _ptr(out),
+            rc = lib.pn2_group_points(_ptr(xyz), _ptr(new_xyz), _ptr(points), _ptr(idx), B, N, S, K, D, _ptr(out), ldg,
                                       _ptr(_err_word(dev)), _stream(dev))
         _lib.check(rc, "pn2_group_points")
         ctx.save_for_backward(idx)
@@ -240,16 +248,16 @@ class _GroupPoints(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         N, D = ctx.shape
         if D == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None
-        return None, None, index_points_backward(gout, idx, N, D, col0=3), None
+            return None, None, None, None, None
+        return None, None, index_points_backward(gout, idx, N, D, col0=3), None, None
 
 
-def group_points(xyz, new_xyz, points, idx):
+def group_points(xyz, new_xyz, points, idx, pad_to=1):
     """[xyz[idx]-new_xyz, points[idx]] for a given idx (models/pointnet2_utils.py:127-132)."""
     dev = _dev(xyz, new_xyz, points, idx)
     if points is not None:
         points = points.to(torch.float32).contiguous()
-    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx))
+    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to)
     _after_fault_op(dev, "group_points")
     return out
 

@@ -42,9 +42,10 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pn2_farthest_point_sample(one, 1, 0, 2, one, one, null, null, null) == -2
     assert lib.pn2_farthest_point_sample(one, 1, 40000, 2, one, one, null, null, null) == -3
     assert lib.pn2_farthest_point_sample(one, 0, 8, 2, one, one, null, null, null) == 0      # empty batch
-    assert lib.pn2_ball_query_group(0.1, 65, one, one, null, 1, 8, 2, 0, one, null, null, null) == -3
-    assert lib.pn2_ball_query_group(0.1, 8, one, one, null, 1, 8, 2, 3, one, null, null, null) == -1   # D>0, no points
-    assert lib.pn2_ball_query_group(0.1, 0, one, one, null, 1, 8, 2, 0, one, null, null, null) == -2
+    assert lib.pn2_ball_query_group(0.1, 65, one, one, null, 1, 8, 2, 0, one, null, 0, null, null) == -3
+    assert lib.pn2_ball_query_group(0.1, 8, one, one, null, 1, 8, 2, 3, one, null, 0, null, null) == -1   # D>0, no points
+    assert lib.pn2_ball_query_group(0.1, 0, one, one, null, 1, 8, 2, 0, one, null, 0, null, null) == -2
+    assert lib.pn2_ball_query_group(0.1, 8, one, one, one, 1, 8, 2, 3, one, one, 5, null, null) == -2    # pitch < 3+D
     assert lib.pn2_three_nn(one, one, 1, 8, 2, one, null, one, null) == -2                   # S < 3
     assert lib.pn2_index_points_backward(one, one, 1, 8, 4, 3, 6, 3, one, null) == -2        # col0+D > Cg
     assert lib.pn2_index_points(one, one, 1, 8, 4, 0, one, null, null) == 0                  # M == 0
