@@ -134,10 +134,12 @@ int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int
 
 /* partial[P][2][C] -> train-mode BatchNorm coefficients scale = gamma*invstd, shift = beta -
  * mean*scale (biased variance), mean/invstd for backward, and the running-estimate update
- * running = (1-momentum)*running + momentum*batch (unbiased variance), nn.BatchNorm semantics. */
+ * running = (1-momentum)*running + momentum*batch (unbiased variance), nn.BatchNorm semantics;
+ * num_batches_tracked (nullable, int64 device word) is incremented. */
 int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma, const float *beta,
                     float eps, float momentum, float *running_mean, float *running_var, float *scale,
-                    float *shift, float *mean_out, float *invstd_out, pn2_stream_t stream);
+                    float *shift, float *mean_out, float *invstd_out, long long *num_batches_tracked,
+                    pn2_stream_t stream);
 
 /* eval-mode coefficients from the running estimates */
 int pn2_bn_eval_coeff(int C, const float *gamma, const float *beta, const float *running_mean,

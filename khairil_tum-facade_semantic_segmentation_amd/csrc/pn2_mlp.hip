@@ -258,8 +258,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
     constexpr int NB = BN / 32;
     constexpr int LDBT = BN + 4;
     constexpr int SB_ELEMS = WT ? MLP_BK * LDBT : BN * MLP_LD;
-    __shared__ __attribute__((aligned(16))) float sA[MLP_BM * MLP_LD];
-    __shared__ __attribute__((aligned(16))) float sB[SB_ELEMS];
+    constexpr int SA_ELEMS = MLP_BM * MLP_LD;
+    __shared__ __attribute__((aligned(16))) float sAbuf[2 * SA_ELEMS];     // double-buffered: step s reads
+    __shared__ __attribute__((aligned(16))) float sBbuf[2 * SB_ELEMS];     // half s&1 while s+1 is written
     __shared__ float sRed[4][2][BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -331,6 +332,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
     auto commit = [&](int step) {
         const int t = step / nk;
         const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM;
+        float *sA = sAbuf + (step & 1) * SA_ELEMS;
+        float *sB = sBbuf + (step & 1) * SB_ELEMS;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 v = ra[i];
@@ -384,11 +387,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
     }
 
-    if (nsteps > 0) issue(0);
-    for (int step = 0; step < nsteps; ++step) {
-        commit(step);
+    if (nsteps > 0) {
+        issue(0);
+        commit(0);
         __syncthreads();
+    }
+    for (int step = 0; step < nsteps; ++step) {
         if (step + 1 < nsteps) issue(step + 1);                  // next step's loads fly under the MFMAs
+        const float *sA = sAbuf + (step & 1) * SA_ELEMS;
+        const float *sB = sBbuf + (step & 1) * SB_ELEMS;
         const float *aRow = &sA[(wave * 32 + l31) * MLP_LD + 16 * half];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -448,7 +455,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
             }
         }
-        __syncthreads();
+        if (step + 1 < nsteps) commit(step + 1);                 // into the other LDS half
+        __syncthreads();                                         // the only barrier of the step
     }
     if (!p.stat_partial) return;
 #pragma unroll
@@ -476,8 +484,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
                                                           float eps, float momentum, float *__restrict__ running_mean,
                                                           float *__restrict__ running_var, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ mean_out,
-                                                          float *__restrict__ invstd_out)
+                                                          float *__restrict__ invstd_out, long long *num_batches_tracked)
 {
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     __shared__ double sS[32][33], sQ[32][33];
     const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 32 partial slices
     const int c = blockIdx.x * 32 + cl;
@@ -623,7 +632,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
     const int c4 = (tid & 15) * 4, rb = tid >> 4;
     const int n4 = n0 + c4, k4 = k0 + c4;
     const bool n_ok = n4 < p.N;                      // N % 4 == 0 on this path
-    const bool k_act = k4 < Kact, k_one = k4 == Kact;
+    const bool k_act = k4 < Kact, k_one = !VEC4 && k4 == Kact;
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);      // VEC4: running column sums of dz (bias gradient)
     const bool from1 = k4 < p.K1;
     float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, is = sc, a1 = sc, a2 = sc, asc = sc, ash = sc;
     if (VEC4) {
@@ -641,31 +651,37 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
         }
     }
 
+    float4 gv[8], zv[8], xv[8];
+    uchar4 av[8];
+    // VEC4: global loads of a tile into registers (issued one tile ahead of their use)
+    auto issue = [&](int tile) {
+        const int row0 = tile * MLP_BM;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + rb + 16 * i;
+            const bool rok = row < p.M;
+            gv[i] = zv[i] = xv[i] = make_float4(0, 0, 0, 0);
+            av[i] = make_uchar4(255, 255, 255, 255);
+            if (rok && n_ok) {
+                if (p.argk) {
+                    const int cent = row / p.pool_k;
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4);
+                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4);
+                } else {
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4);
+                }
+                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4);
+            }
+            if (rok && k_act)
+                xv[i] = from1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k4)
+                              : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k4 - p.K1));
+        }
+    };
+    if (VEC4 && (int)blockIdx.x < ntiles) issue(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * MLP_BM;
         if (VEC4) {
-            float4 gv[8], zv[8], xv[8];
-            uchar4 av[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = row0 + rb + 16 * i;
-                const bool rok = row < p.M;
-                gv[i] = zv[i] = xv[i] = make_float4(0, 0, 0, 0);
-                av[i] = make_uchar4(255, 255, 255, 255);
-                if (rok && n_ok) {
-                    if (p.argk) {
-                        const int cent = row / p.pool_k;
-                        gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4);
-                        av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4);
-                    } else {
-                        gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4);
-                    }
-                    zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4);
-                }
-                if (rok && k_act)
-                    xv[i] = from1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k4)
-                                  : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k4 - p.K1));
-            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int r = rb + 16 * i;
@@ -685,6 +701,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 #define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
                         PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
 #undef PN2_DZ
+                        dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
                     }
                     if (k_act) {
                         av4 = xv[i];
@@ -701,6 +718,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
                 *reinterpret_cast<float4 *>(&sD[r * DW_LD + c4]) = dv;
                 *reinterpret_cast<float4 *>(&sX[r * DW_LD + c4]) = av4;
             }
+            __syncthreads();
+            if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's loads fly under the MFMAs
         } else {
             for (int e = tid; e < MLP_BM * 64; e += MLP_THREADS) {
                 const int r = e >> 6, c = e & 63;
@@ -731,8 +750,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
                 sD[r * DW_LD + c] = dv;
                 sX[r * DW_LD + c] = xv;
             }
+            __syncthreads();
         }
-        __syncthreads();
         // MFMA: i = n (dz column), j = k (act column), reduction over this wave's 32 rows
         const float *dBase = &sD[(wave * 32 + 16 * half) * DW_LD];
         const float *xBase = &sX[(wave * 32 + 16 * half) * DW_LD];
@@ -766,9 +785,23 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
         __syncthreads();
     }
     float *out = p.partial + (size_t)blockIdx.x * p.N * Kout;
+    const int klim = VEC4 ? Kact : Kout;                         // VEC4: the bias column comes from dbs below
     for (int e = tid; e < 64 * 64; e += MLP_THREADS) {
         const int n = e >> 6, k = e & 63;
-        if (n0 + n < p.N && k0 + k < Kout) out[(size_t)(n0 + n) * Kout + k0 + k] = red[n * DW_LD + k];
+        if (n0 + n < p.N && k0 + k < klim) out[(size_t)(n0 + n) * Kout + k0 + k] = red[n * DW_LD + k];
+    }
+    if (VEC4 && blockIdx.z == 0) {
+        // 16 threads (rb = 0..15) hold partial sums for the same 4 columns: combine through LDS
+        __syncthreads();
+        float *cs = sX;                                           // [16][64]
+        *reinterpret_cast<float4 *>(&cs[rb * 64 + c4]) = dbs;
+        __syncthreads();
+        if (tid < 64 && n0 + tid < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += cs[i * 64 + tid];
+            out[(size_t)(n0 + tid) * Kout + Kact] = t;
+        }
     }
 }
 
@@ -964,7 +997,7 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
 PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean,
                                float *running_var, float *scale, float *shift, float *mean_out, float *invstd_out,
-                               pn2_stream_t stream_)
+                               long long *num_batches_tracked, pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(partial);
     PN2_REQUIRE_PTR(scale);
@@ -972,7 +1005,7 @@ PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count,
     if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_), partial,
                        P, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
-                       invstd_out);
+                       invstd_out, num_batches_tracked);
     return PN2_LAUNCH_RC();
 }
 
@@ -1015,7 +1048,7 @@ PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
 {
     // ~1024 workgroups in flight: the M axis is split so that (M slabs) x (64x64 output blocks) ~ 1024
     const int ntiles = (M + MLP_BM - 1) / MLP_BM;
-    const int blocks = ((N + DW_BN - 1) / DW_BN) * ((K + 1 + DW_BK - 1) / DW_BK);
+    const int blocks = ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK);
     int p = 1024 / (blocks < 1 ? 1 : blocks);
     if (p < 8) p = 8;
     if (p > ntiles) p = ntiles;
@@ -1054,8 +1087,12 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
     if (ascale) vec4 = vec4 && aligned16(ascale) && aligned16(ashift);
     if (argk) vec4 = vec4 && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
-    if (vec4) hipLaunchKernelGGL(mlp_dw_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL(mlp_dw_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
+    if (vec4) {
+        grid.z = (unsigned)((K + DW_BK - 1) / DW_BK);             // the bias column is summed on the side
+        hipLaunchKernelGGL(mlp_dw_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(mlp_dw_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
+    }
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK) return rc;
     const int total = N * (K + 1);

@@ -64,10 +64,10 @@ class _MLPStack(torch.autograd.Function):
                     rc = lib.pn2_bn_finalize(_ptr(stat), P, Co, float(M), _ptr(gamma), _ptr(beta), float(bn.eps), mom,
                                              _ptr(bn.running_mean) if track else None,
                                              _ptr(bn.running_var) if track else None, _ptr(scale), _ptr(shift),
-                                             _ptr(mean), _ptr(invstd), _stream(dev))
+                                             _ptr(mean), _ptr(invstd),
+                                             _ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else None,
+                                             _stream(dev))
                     _lib.check(rc, "pn2_bn_finalize")
-                    if track and bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked.add_(1)
                     coefs.append((scale, shift, mean, invstd))
                 else:
                     rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
