@@ -145,6 +145,14 @@ def main():
     k_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
     algo = ball_group_algorithmic_bytes(PER_GPU_BATCH, BLOCK_POINTS, 1024, 32, CHANNELS)
     achieved = algo / (k_ms * 1e-3) / 1e9
+    # HBM traffic of that launch cannot be read from inside this process: it is the rocprofv3 --pmc
+    # measurement committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01", "ball_query_pmc.json")) as fh:
+            traffic = json.load(fh).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
 
     if rank == 0:
         total_points = world * PER_GPU_BATCH * BLOCK_POINTS * args.steps
@@ -167,7 +175,7 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "kernel": "ball_query_group_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": algo, "kernel_ms": k_ms},
+                         "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": k_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
