@@ -14,6 +14,12 @@
 
 #include "pn2_common.h"
 
+namespace pn2 {
+int launch_ball_query_mfma(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
+                           int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
+                           hipStream_t stream);
+}
+
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -384,6 +390,12 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
     // each takes several centroids.  Few centroids (deep levels): small workgroups, two
     // centroids per wave, for parallelism.
     const long long total = (long long)B * S;
+    // Many centroids over a block that fits LDS: the matrix-core kernel (pn2_ball_mfma.hip).
+    if (total >= 4096 && pn2::tune_get("bq_mfma", 1)) {
+        const int rc = pn2::launch_ball_query_mfma(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped,
+                                                   err_count, stream);
+        if (rc != PN2_ERR_UNSUPPORTED) return rc;
+    }
     const int cfg = pn2::tune_get("bq_cfg", total >= 8192 ? 3 : (total >= 2048 ? 1 : 2));
     // Few centroids with wide rows (deep levels): the gather is latency-bound inside the scan
     // waves, so the scan kernel writes idx only and a fully parallel elementwise kernel groups.

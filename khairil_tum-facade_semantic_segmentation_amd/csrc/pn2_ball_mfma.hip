@@ -1,0 +1,288 @@
+// query_ball_point + grouping, matrix-core form of the pair test (gfx950).
+//
+// The reference computes the [S,N] distance matrix with a matmul (models/pointnet2_utils.py:37)
+// and adds the norms (:38-39); the VALU kernel in pn2_ball_group.hip spends 6 vector
+// instructions per 64 pairs on that expression and is bound by vector-instruction issue
+// (rocprofv3 PMC).  Here the exact expression is evaluated by the matrix pipe:
+//
+//     f = fma(1, r2, fma(1, -|p|^2, fma(-|c|^2, 1, fma(2cz, pz, fma(2cy, py, fma(2cx, px, 0))))))
+//                                                              three v_mfma_f32_32x32x2_f32
+//
+// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fma chain (cdna_hip_programming.md
+// section 3); scaling by 2 and negation commute with round-to-nearest, so the chain holds, step by
+// step, 2*dot, -((-2*dot) + |c|^2), -dist and finally round(r2 - dist) with `dist` exactly the
+// reference's value (:37-39).  A point is inside the ball (not masked at :102) iff dist <= r2 iff
+// the sign bit of f is clear (r2 - dist == +0 when equal).  32 centroids x 32 points per MFMA
+// triple; the vector unit only collects 16 sign bits per lane (v_alignbit_b32).
+//
+// Work split: a 512-thread workgroup = 2 centroid groups (32 each) x 4 point quarters; every
+// wave scans its quarter for its 32 centroids and appends hits to a per-(centroid, quarter)
+// sub-list with LDS atomics; sub-lists are verified ascending (re-ranked if an atomic pair landed
+// out of order), concatenated in quarter order and truncated to nsample, which is exactly "the
+// nsample lowest indices" (:103).  Grouping as in pn2_ball_group.hip.
+#include <math.h>
+
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MF_THREADS = 512;
+constexpr int MF_WAVES = 8;
+constexpr int MF_CENT = 64;                   // centroids per workgroup (2 groups of 32)
+constexpr int MF_MAXN = 4096;                 // whole block resident in LDS as SoA x,y,z,|p|^2
+
+__global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
+    int B, int N, int S, int K, int D, int ldg, float r2, int tiles_per_block, unsigned ldg_magic,
+    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NT = (N + 127) & ~127;                              // 4 quarters of a multiple of 32
+    const int NQ = NT >> 2;
+    const int cap = K + 32;                                       // sub-list capacity (see header)
+    float *sX = reinterpret_cast<float *>(smem);
+    float *sY = sX + NT;
+    float *sZ = sY + NT;
+    float *sP = sZ + NT;                                          // -|p|^2 (-inf on padding)
+    unsigned *cnt = reinterpret_cast<unsigned *>(sP + NT);        // [64][4]
+    int *merged = reinterpret_cast<int *>(cnt + MF_CENT * 4);     // [64][K] ushort merged lists (MF_CENT*K/2 ints)
+    unsigned short *lists = reinterpret_cast<unsigned short *>(merged + MF_CENT * K / 2 + 2);   // [64][4][cap]
+
+    const unsigned logical = pn2::xcd_remap(blockIdx.x, gridDim.x);
+    const int b = (int)(logical / (unsigned)tiles_per_block);
+    const int tile = (int)(logical % (unsigned)tiles_per_block);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, quarter = wave & 3;
+    const int s_base = tile * MF_CENT;
+
+    const float *bx = xyz + (size_t)b * N * 3;
+    const float *bc = new_xyz + (size_t)b * S * 3;
+
+    // ---- stage the block (all loads of a thread issued first) ----------------------------------
+    {
+        constexpr int PT = MF_MAXN / MF_THREADS;
+        float sx[PT], sy[PT], sz[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = tid + i * MF_THREADS;
+            const int jj = j < N ? j : 0;
+            sx[i] = bx[jj * 3 + 0];
+            sy[i] = bx[jj * 3 + 1];
+            sz[i] = bx[jj * 3 + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int j = tid + i * MF_THREADS;
+            if (j < NT) {
+                const bool in = j < N;
+                sX[j] = in ? sx[i] : 0.0f;
+                sY[j] = in ? sy[i] : 0.0f;
+                sZ[j] = in ? sz[i] : 0.0f;
+                sP[j] = in ? -pn2::norm3(sx[i], sy[i], sz[i]) : -INFINITY;     // padding: f = -inf, never a hit
+            }
+        }
+        if (tid < MF_CENT * 4) cnt[tid] = 0;
+    }
+
+    // ---- A operands: lane l -> centroid i = l&31 of this wave's group, k = l>>5 -----------------
+    const int my_s = s_base + grp * 32 + l31;
+    const bool s_ok = my_s < S;
+    const int sc = s_ok ? my_s : S - 1;
+    const float cx = bc[sc * 3 + 0], cy = bc[sc * 3 + 1], cz = bc[sc * 3 + 2];
+    const float a1 = half ? 2.0f * cy : 2.0f * cx;               // MFMA 1: k0 = 2cx*px, k1 = 2cy*py
+    const float a2 = half ? -pn2::norm3(cx, cy, cz) : 2.0f * cz; // MFMA 2: k0 = 2cz*pz, k1 = -|c|^2 * 1
+                                                                 // MFMA 3: k0 = 1 * -|p|^2, k1 = 1 * r2
+    __syncthreads();
+
+    // ---- scan this wave's quarter: 32 points per step; the MFMAs of step t+1 are issued before the
+    //      vector work of step t so the matrix pipe's latency hides under it ---------------------
+    const float *pxy = (half ? sY : sX) + quarter * NQ + l31;
+    const float *pz = sZ + quarter * NQ + l31;
+    const float *pn = sP + quarter * NQ + l31;
+    const int nsteps = (dbg & 1) ? 0 : NQ >> 5;
+    const unsigned rows_valid = (unsigned)max(0, min(32, S - (s_base + grp * 32)));   // rows < rows_valid exist
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+
+    // one step = 32 points: issue(t) puts the three MFMAs of step t in flight, consume() turns an
+    // accumulator into hit bits and appends; the loop is unrolled by two so that the MFMAs of the
+    // next step are issued before the vector work of the current one (no register copies).
+    auto issue = [&](int t) -> f32x16 {
+        const float bxy = pxy[t * 32], bz = pz[t * 32], nnp = pn[t * 32];
+        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bxy, zero16, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, half ? 1.0f : bz, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, half ? r2 : nnp, a, 0, 0, 0);
+        return a;
+    };
+    auto consume = [&](const f32x16 &f, int t) {
+        // sign bit of f = round(r2 - dist): set <=> dist > r2 <=> masked out (:102); reg r -> bit 15-r
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(f[r]), 31);
+        unsigned hits = ~bits & 0xffffu;
+        if (dbg & 2) hits = 0;
+        if (__ballot(hits != 0)) {
+            const int j = quarter * NQ + t * 32 + l31;
+            while (hits) {                                      // this lane's point is inside >= 1 ball
+                const int pbit = __builtin_ctz(hits);
+                hits &= hits - 1;
+                const int r = 15 - pbit;
+                const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2) + 4 * half);   // C/D row of register r
+                if (row < rows_valid) {
+                    const int c = grp * 32 + (int)row;
+                    const unsigned pos = atomicAdd(&cnt[c * 4 + quarter], 1u);
+                    if (pos < (unsigned)cap) lists[(c * 4 + quarter) * cap + pos] = (unsigned short)j;
+                }
+            }
+        }
+    };
+    if (nsteps > 0) {
+        f32x16 fa = issue(0), fb = zero16;
+        int t = 0;
+        for (; t + 2 <= nsteps; t += 2) {                       // nsteps = NQ/32 is even (NQ % 64 == 0)? no: handle tail below
+            fb = issue(t + 1);
+            consume(fa, t);
+            if (t + 2 < nsteps) fa = issue(t + 2);
+            consume(fb, t + 1);
+        }
+        if (t < nsteps) consume(fa, t);
+    }
+    __syncthreads();
+    if (dbg & 4) return;
+
+    // ---- (1) every sub-list must be ascending: arrival order is, except that two hits of one
+    //      32-point step may have landed swapped.  One thread per (centroid, quarter) checks and,
+    //      if needed, insertion-sorts its sub-list (rare, short). ---------------------------------
+    if (tid < MF_CENT * 4) {
+        const int nq = (int)min(cnt[tid], (unsigned)cap);
+        unsigned short *L = lists + tid * cap;
+        bool bad = false;
+        for (int k = 0; k + 1 < nq; ++k) bad = bad || (L[k] > L[k + 1]);
+        if (bad) {
+            for (int k = 1; k < nq; ++k) {
+                const unsigned short v = L[k];
+                int m = k - 1;
+                while (m >= 0 && L[m] > v) { L[m + 1] = L[m]; --m; }
+                L[m + 1] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- (2) merged list = sub-lists in quarter order, first K, padded with the first (:103-106);
+    //      one thread per output slot -> idx (int64, coalesced) and an LDS copy for grouping ------
+    unsigned short *mlist = reinterpret_cast<unsigned short *>(merged);        // [64][K], 0xffff = empty ball
+    for (int e = tid; e < MF_CENT * K; e += MF_THREADS) {
+        const int c = e / K, k = e - c * K;
+        const int s = s_base + c;
+        if (s >= S) continue;
+        const int n0 = (int)min(cnt[c * 4 + 0], (unsigned)cap), n1 = (int)min(cnt[c * 4 + 1], (unsigned)cap);
+        const int n2 = (int)min(cnt[c * 4 + 2], (unsigned)cap), n3 = (int)min(cnt[c * 4 + 3], (unsigned)cap);
+        const int total = n0 + n1 + n2 + n3;
+        const int kk = k < total ? k : 0;                       // pad with the first hit
+        int q, off;
+        if (kk < n0) { q = 0; off = kk; }
+        else if (kk < n0 + n1) { q = 1; off = kk - n0; }
+        else if (kk < n0 + n1 + n2) { q = 2; off = kk - n0 - n1; }
+        else { q = 3; off = kk - n0 - n1 - n2; }
+        int64_t v = N;                                          // reference: IndexError at :59
+        unsigned short vs = 0xffff;
+        if (total > 0) { vs = lists[(c * 4 + q) * cap + off]; v = vs; }
+        else if (k == 0 && err_count) atomicAdd(err_count, 1);
+        idx[((size_t)b * S + s) * K + k] = v;
+        mlist[e] = vs;
+    }
+    if (!grouped) return;
+    __syncthreads();
+
+    // ---- (3) grouped rows, one element group per thread over the whole workgroup ---------------
+    const int Cg = 3 + D;
+    const int row_elems = K * ldg;
+    const float *bp = points ? points + (size_t)b * N * D : nullptr;
+    const int ncent = min(MF_CENT, S - s_base);
+    float *gbase = grouped + ((size_t)b * S + s_base) * row_elems;
+    if (ldg == Cg && (Cg & 3) == 0 && ((reinterpret_cast<uintptr_t>(grouped) & 15) == 0)) {
+        // rows of 4*qpr floats: one float4 per thread and step; quad 0 = [xyz - centroid, feat0]
+        const int qpr = Cg >> 2;
+        const int per_c = K * qpr;
+        float4 *g4 = reinterpret_cast<float4 *>(gbase);
+        for (int e = tid; e < ncent * per_c; e += MF_THREADS) {
+            const int rowk = qpr == 1 ? e : (int)__umulhi((unsigned)e, ldg_magic);      // e / qpr = c*K + k
+            const int part = e - rowk * qpr;
+            const unsigned short js = mlist[rowk];
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (js != 0xffff) {
+                const int j = js;
+                const float *row = bp + (size_t)j * D;
+                if (part == 0) {
+                    const int c = rowk / K;
+                    const float *cc = bc + (size_t)(s_base + c) * 3;
+                    v = make_float4(sX[j] - cc[0], sY[j] - cc[1], sZ[j] - cc[2], row[0]);       // :128, :131
+                } else {
+                    const float *src = row + (4 * part - 3);
+                    v = make_float4(src[0], src[1], src[2], src[3]);
+                }
+            }
+            g4[e] = v;
+        }
+    } else {
+        // generic pitch: element (row = c*K + k, col); col < 3 xyz, col < Cg feats, else zero pad
+        const long long total = (long long)ncent * K * ldg;
+        for (long long e = tid; e < total; e += MF_THREADS) {
+            const int rowk = (int)(e / ldg), col = (int)(e - (long long)rowk * ldg);
+            const unsigned short js = mlist[rowk];
+            float v = 0.0f;
+            if (js != 0xffff && col < Cg) {
+                const int j = js;
+                if (col < 3) {
+                    const int c = rowk / K;
+                    const float pv = col == 0 ? sX[j] : (col == 1 ? sY[j] : sZ[j]);
+                    v = pv - bc[(size_t)(s_base + c) * 3 + col];                               // :128
+                } else {
+                    v = bp[(size_t)j * D + (col - 3)];                                         // :131-132
+                }
+            }
+            gbase[e] = v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace pn2 {
+
+// Returns PN2_ERR_UNSUPPORTED when the shape is outside what this kernel is built for (the caller
+// then uses the vector-unit kernel).
+int launch_ball_query_mfma(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
+                           int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
+                           hipStream_t stream)
+{
+    if (N > MF_MAXN || K > 64) return PN2_ERR_UNSUPPORTED;
+    // the workgroup-wide grouping pass is built for rows of 4*q floats (SA1: 3+9 = 12); other row
+    // shapes go through the vector-unit kernel / the element-wise grouping kernel
+    if (grouped && !(ldg == 3 + D && ((3 + D) & 3) == 0)) return PN2_ERR_UNSUPPORTED;
+    const int NT = (N + 127) & ~127;
+    const int cap = K + 32;
+    const size_t lds = (size_t)NT * 4 * sizeof(float) + MF_CENT * 4 * sizeof(unsigned) + ((size_t)MF_CENT * K / 2 + 2) * sizeof(int) +
+                       (size_t)MF_CENT * 4 * cap * sizeof(unsigned short);
+    if (lds > 160 * 1024) return PN2_ERR_UNSUPPORTED;
+    const int tiles = (S + MF_CENT - 1) / MF_CENT;
+    const long long nwg = (long long)B * tiles;
+    if (nwg > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
+    const int Cg = 3 + D;
+    const int qpr = (ldg == Cg && (Cg & 3) == 0) ? (Cg >> 2) : 1;
+    const unsigned magic = qpr > 1 ? (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u : 0u;     // e/qpr exact for e*qpr < 2^32
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ball_query_group_mfma_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ball_query_group_mfma_kernel, dim3((unsigned)nwg), dim3(MF_THREADS), lds, stream, xyz, new_xyz,
+                       points, B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
+    return PN2_LAUNCH_RC();
+}
+
+}  // namespace pn2
