@@ -5,6 +5,8 @@ when the backend is "nccl") of a flat fp32 gradient buffer per step (SURVEY.md 8
 The reference has no distributed code (single process, sem_seg_training.py:374); the step body
 restates localfunctions.py:203-218: zero_grad -> forward -> nll_loss(weight) -> backward -> Adam
 (sem_seg_training.py:576-582).  BatchNorm statistics stay rank-local (no SyncBN upstream)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -42,7 +44,7 @@ class FlatGradients:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and os.environ.get("PN2_FORCE_DP_PATH", "0") != "1":
             return
         flat = self.pack()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -92,6 +94,12 @@ class SemSegTrainer:
             return dist.get_world_size(self.group)
         return 1
 
+    def _exchange(self):
+        """True when gradients go through the packed-buffer all-reduce.  PN2_FORCE_DP_PATH=1 takes
+        that path with a single rank too (rehearsal of the N > 1 code on a one-GPU box)."""
+        return self._world() > 1 or (os.environ.get("PN2_FORCE_DP_PATH", "0") == "1"
+                                     and dist.is_available() and dist.is_initialized())
+
     def _launch_prefetch(self, next_blocks_cf):
         """Enqueue the geometry pyramid of `next_blocks_cf` on the side stream."""
         main = torch.cuda.current_stream()
@@ -127,7 +135,7 @@ class SemSegTrainer:
         return loss
 
     def _capture(self, blocks_cf, target):
-        world = self._world()
+        exchange = self._exchange()
         self._static_x = blocks_cf.clone()
         self._static_y = target.clone()
         if self.prefetch:
@@ -154,11 +162,11 @@ class SemSegTrainer:
             self._static_loss = self._forward_backward(self._static_x, self._static_y, geo)
             if self.prefetch:
                 torch.cuda.current_stream().wait_stream(self._side)       # join
-            if world > 1:
+            if exchange:
                 self.grads.pack()                       # .grad become views of one flat buffer
             else:
                 self.optimizer.step()
-        if world > 1:
+        if exchange:
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, pool=pool):
                 self.optimizer.step()
