@@ -172,6 +172,15 @@ int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long lon
 int pn2_bn_bwd_finalize(const float *partial, int P, int C, double count, float *dgamma, float *dbeta,
                         float *c1, float *c2, pn2_stream_t stream);
 
+/* ---- whole-scene inference aggregation --------------------------------------
+ * add_vote(vote_label_pool, point_idx, pred_label, weight)            localfunctions.py:339-346
+ * vote_pool[P][C] int32 += 1 at (point_idx[m], label[m]) for every m < M whose weight is neither 0
+ * nor inf (weight nullable = all ones).  label = arg-max over the C log-probabilities of row m of
+ * logp (first maximum wins, the `seg_pred.max(2)[1]` of localfunctions.py:399) or, when logp is
+ * NULL, pred_label[m].  Out-of-range point index / label: skipped, err_count += 1. */
+int pn2_add_vote(const float *logp, const int64_t *pred_label, const int64_t *point_idx, const float *weight,
+                 long long M, int C, long long P, int32_t *vote_pool, int32_t *err_count, pn2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,194 @@
+"""Host/device pieces either side of the hot path: the training block sampler, the
+whole-scene sliding-window tiler and the vote aggregation of whole-scene inference.
+
+The reference does an `np.where` over the ENTIRE scene for every block / window
+(sem_seg_training.py:211, sem_seg_testing.py:202) and adds votes in a Python double loop
+(localfunctions.py:339-346); at GPU speeds those, not the network, bound end-to-end throughput.
+Here the scene's points are bucketed once into a 2-D grid so a window touches only the cells it
+overlaps, and votes are scattered on the device straight from the network's log-probabilities.
+Block / window semantics and the numpy RNG call sequence are those of the reference, so the same
+seed yields the same blocks (tests/test_scene_cpu.py, against outputs of the reference's code)."""
+import numpy as np
+
+
+class GridIndex:
+    """Points of one scene bucketed by (x, y) cell; query(xmin, xmax, ymin, ymax) returns the
+    indices of the points inside the closed window in ascending order -- what
+    `np.where(mask)[0]` yields in the reference -- touching only the overlapped cells."""
+
+    def __init__(self, xy, cell=0.25):
+        xy = np.asarray(xy, dtype=np.float64)
+        self.xy = xy
+        self.cell = float(cell)
+        self.origin = xy.min(axis=0)
+        ij = np.floor((xy - self.origin) / self.cell).astype(np.int64)
+        self.nx, self.ny = int(ij[:, 0].max()) + 1, int(ij[:, 1].max()) + 1
+        key = ij[:, 1] * self.nx + ij[:, 0]
+        order = np.argsort(key, kind="stable")                 # stable: ascending index inside a cell
+        self.order = order
+        self.start = np.searchsorted(key[order], np.arange(self.nx * self.ny + 1), side="left")
+
+    def query(self, xmin, xmax, ymin, ymax):
+        c = self.cell
+        i0 = max(int(np.floor((xmin - self.origin[0]) / c)), 0)
+        i1 = min(int(np.floor((xmax - self.origin[0]) / c)), self.nx - 1)
+        j0 = max(int(np.floor((ymin - self.origin[1]) / c)), 0)
+        j1 = min(int(np.floor((ymax - self.origin[1]) / c)), self.ny - 1)
+        if i1 < i0 or j1 < j0:
+            return np.empty(0, dtype=np.int64)
+        parts = [self.order[self.start[j * self.nx + i0]:self.start[j * self.nx + i1 + 1]] for j in range(j0, j1 + 1)]
+        cand = np.concatenate(parts)
+        p = self.xy[cand]
+        keep = (p[:, 0] >= xmin) & (p[:, 0] <= xmax) & (p[:, 1] >= ymin) & (p[:, 1] <= ymax)
+        return np.sort(cand[keep])
+
+
+def _extra_columns(extra, feature_name, sel):
+    cols = np.zeros((sel.size, len(extra)))
+    for i, name in enumerate(feature_name):
+        f = extra[i][sel]
+        cols[:, i] = f / 255 if name in ("red", "blue", "green") else f      # sem_seg_testing.py:233-234
+    return cols
+
+
+class SceneTiler:
+    """Sliding-window blocks of a whole scene (TestCustomDataset.__getitem__,
+    sem_seg_testing.py:182-254): windows of block_size at `stride`, clamped to the scene, padded by
+    `padding`; each window's points are topped up to a multiple of block_points and shuffled."""
+
+    def __init__(self, points, labels, extra=(), feature_name=(), labelweights=None, block_points=4096,
+                 block_size=1.0, stride=0.5, padding=0.001):
+        self.points = np.asarray(points, dtype=np.float64)[:, :3]
+        self.labels = np.asarray(labels)
+        self.extra = list(extra)
+        self.feature_name = list(feature_name)
+        self.labelweights = np.ones(int(self.labels.max()) + 1) if labelweights is None else np.asarray(labelweights)
+        self.block_points, self.block_size, self.stride, self.padding = block_points, block_size, stride, padding
+        self.index = GridIndex(self.points[:, :2], cell=block_size / 4.0)
+
+    def tile(self):
+        """-> data [nblocks, block_points, 6+extra], labels, sample weights, point indices."""
+        pts, bs, st, pad, bp = self.points, self.block_size, self.stride, self.padding, self.block_points
+        cmin, cmax = pts.min(axis=0), pts.max(axis=0)
+        gx = int(np.ceil(float(cmax[0] - cmin[0] - bs) / st) + 1)
+        gy = int(np.ceil(float(cmax[1] - cmin[1] - bs) / st) + 1)
+        datas, labs, wts, idxs = [], [], [], []
+        for iy in range(gy):
+            for ix in range(gx):
+                ex = min(cmin[0] + ix * st + bs, cmax[0])
+                sx = ex - bs
+                ey = min(cmin[1] + iy * st + bs, cmax[1])
+                sy = ey - bs
+                sel = self.index.query(sx - pad, ex + pad, sy - pad, ey + pad)
+                if sel.size == 0:
+                    continue
+                size = int(np.ceil(sel.size / bp)) * bp
+                fill = size - sel.size
+                rep = np.random.choice(sel, fill, replace=fill > sel.size)      # :209-210
+                sel = np.concatenate((sel, rep))
+                np.random.shuffle(sel)                                         # :212
+                xyz = pts[sel]
+                block = np.empty((size, 6 + len(self.extra)))
+                block[:, 0] = xyz[:, 0] - (sx + bs / 2.0)
+                block[:, 1] = xyz[:, 1] - (sy + bs / 2.0)
+                block[:, 2] = xyz[:, 2]
+                block[:, 3:6] = xyz / cmax
+                if self.extra:
+                    block[:, 6:] = _extra_columns(self.extra, self.feature_name, sel)
+                lab = self.labels[sel].astype(int)
+                datas.append(block)
+                labs.append(lab)
+                wts.append(self.labelweights[lab])
+                idxs.append(sel)
+        data = np.concatenate(datas).reshape(-1, bp, 6 + len(self.extra))
+        return (data, np.concatenate(labs).reshape(-1, bp), np.concatenate(wts).reshape(-1, bp),
+                np.concatenate(idxs).reshape(-1, bp))
+
+
+class BlockSampler:
+    """Random training blocks of one room (TrainCustomDataset.__getitem__, sem_seg_training.py:200-259):
+    a block_size column around a random point, re-drawn until it holds > 1024 points, num_point of
+    them sampled (with replacement only if there are fewer); x, y centred, xyz / room_max appended."""
+
+    def __init__(self, points, labels, extra=(), feature_name=(), num_point=4096, block_size=1.0):
+        self.points = np.asarray(points, dtype=np.float64)[:, :3]
+        self.labels = np.asarray(labels)
+        self.extra = list(extra)
+        self.feature_name = list(feature_name)
+        self.num_point, self.block_size = num_point, block_size
+        self.coord_max = self.points.max(axis=0)
+        self.index = GridIndex(self.points[:, :2], cell=block_size / 4.0)
+
+    def sample(self):
+        pts, half = self.points, self.block_size / 2.0
+        while True:
+            center = pts[np.random.choice(pts.shape[0])]
+            sel = self.index.query(center[0] - half, center[0] + half, center[1] - half, center[1] + half)
+            if sel.size > 1024:
+                break
+        chosen = np.random.choice(sel, self.num_point, replace=sel.size < self.num_point)
+        xyz = pts[chosen]
+        out = np.empty((self.num_point, 6 + len(self.extra)))
+        out[:, 0] = xyz[:, 0] - center[0]
+        out[:, 1] = xyz[:, 1] - center[1]
+        out[:, 2] = xyz[:, 2]
+        out[:, 3:6] = xyz / self.coord_max
+        if self.extra:
+            out[:, 6:] = _extra_columns(self.extra, self.feature_name, chosen)
+        return out, self.labels[chosen]
+
+
+class VotePool:
+    """vote_label_pool of modelTesting (localfunctions.py:373-403) kept on the device as int32
+    [num_points, num_classes]; add() scatters one vote per (point, arg-max class) with the HIP
+    kernel behind pn2_add_vote."""
+
+    def __init__(self, num_points, num_classes, device):
+        import torch
+        self.torch = torch
+        self.pool = torch.zeros((num_points, num_classes), dtype=torch.int32, device=device)
+
+    def add(self, logp=None, point_idx=None, weight=None, pred_label=None):
+        from . import _lib
+        from .ops import _dev, _err_word, _ptr, _stream
+        torch = self.torch
+        dev = _dev(logp, pred_label, point_idx, weight, self.pool)
+        lib = _lib.load()
+        P, C = self.pool.shape
+        idx = point_idx.to(torch.int64).contiguous()
+        M = idx.numel()
+        lp = None if logp is None else logp.detach().to(torch.float32).contiguous()
+        pl = None if pred_label is None else pred_label.to(torch.int64).contiguous()
+        w = None if weight is None else weight.to(torch.float32).contiguous()
+        if lp is not None and lp.numel() != M * C:
+            raise ValueError("logp must hold %d x %d values" % (M, C))
+        with torch.cuda.device(dev):
+            rc = lib.pn2_add_vote(_ptr(lp), _ptr(pl), _ptr(idx), _ptr(w), M, C, P, _ptr(self.pool), _ptr(_err_word(dev)),
+                                  _stream(dev))
+        _lib.check(rc, "pn2_add_vote")
+
+    def labels(self):
+        """np.argmax(vote_label_pool, 1) of localfunctions.py:405 (first maximum wins)."""
+        return self.torch.argmax(self.pool, dim=1)
+
+
+def infer_scene(model, data_room, index_room, sample_weight, num_points, num_classes, batch_size=32, num_votes=1,
+                retile=None):
+    """Whole-scene voting inference (localfunctions.py:375-405): run the network over the scene's
+    blocks in sub-batches, vote on the device, return the per-point predicted label tensor.
+    `retile`, if given, is called before every vote round after the first to re-draw the blocks
+    (the reference re-tiles per vote, :377)."""
+    import torch
+    dev = next(model.parameters()).device
+    votes = VotePool(num_points, num_classes, dev)
+    model.eval()
+    with torch.no_grad():
+        for v in range(num_votes):
+            if v > 0 and retile is not None:
+                data_room, _, sample_weight, index_room = retile()
+            for s in range(0, data_room.shape[0], batch_size):
+                x = torch.as_tensor(data_room[s:s + batch_size], dtype=torch.float32, device=dev).transpose(2, 1)
+                logp, _ = model(x)
+                votes.add(logp=logp, point_idx=torch.as_tensor(index_room[s:s + batch_size], device=dev),
+                          weight=torch.as_tensor(sample_weight[s:s + batch_size], dtype=torch.float32, device=dev))
+    return votes.labels()
