@@ -11,6 +11,21 @@ import torch
 import torch.distributed as dist
 
 
+def rotate_z_(blocks_cf, angles=None):
+    """On-device form of provider.rotate_point_cloud_z applied to the xyz channels of a batch
+    (reference localfunctions.py:206, provider.py:66-84): per block a rotation about the up axis by
+    `angles` [B] (default: uniform in [0, 2*pi), drawn on the device), x' = x*cos - y*sin,
+    y' = x*sin + y*cos.  blocks_cf is [B,C,N] channel-first; rotated in place, no host round trip."""
+    B = blocks_cf.shape[0]
+    if angles is None:
+        angles = torch.rand(B, device=blocks_cf.device) * (2.0 * 3.141592653589793)
+    c, s = torch.cos(angles).view(B, 1), torch.sin(angles).view(B, 1)
+    x, y = blocks_cf[:, 0, :].clone(), blocks_cf[:, 1, :].clone()
+    blocks_cf[:, 0, :] = x * c - y * s                  # row-vector @ [[c, s, 0], [-s, c, 0], [0, 0, 1]]
+    blocks_cf[:, 1, :] = x * s + y * c
+    return blocks_cf
+
+
 class FlatGradients:
     """Data-parallel gradient exchange as ONE collective: after backward the per-parameter
     gradients are packed into a contiguous fp32 buffer (one concat kernel, 3.88 MB for

@@ -64,3 +64,19 @@ def test_single_process_is_a_noop():
     net(torch.ones(1, 3)).sum().backward()
     fg.all_reduce_mean()                                    # no process group: nothing to do
     assert fg.buffer is None and fg.numel == 8
+
+
+def test_rotate_z_matches_reference_formula():
+    """provider.rotate_point_cloud_z (provider.py:66-84): rotated = pc @ [[c,s,0],[-s,c,0],[0,0,1]]."""
+    import numpy as np
+    from khairil_tum_facade_semantic_segmentation_amd.train import rotate_z_
+    rs = np.random.RandomState(1)
+    pc = rs.normal(size=(3, 50, 9)).astype(np.float32)
+    ang = rs.uniform(0, 2 * np.pi, size=3)
+    want = pc.copy()
+    for k in range(3):
+        c, s = np.cos(ang[k]), np.sin(ang[k])
+        R = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]])
+        want[k, :, :3] = pc[k, :, :3].reshape(-1, 3) @ R
+    got = rotate_z_(torch.from_numpy(pc).permute(0, 2, 1).contiguous(), torch.from_numpy(ang).float())
+    assert np.abs(got.permute(0, 2, 1).numpy() - want).max() < 1e-5
