@@ -475,6 +475,203 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few-rows form of the pipelined GEMM: 32-row x 128-column tiles, the four waves of a workgroup
+// take one 32-column block each and share the A rows.  Used when M is so small (deep levels:
+// M = 1024..8192) that 128-row tiles would leave most of the 256 CUs idle.  Same prologues,
+// epilogues, statistics and double-buffered staging as mlp_gemm_pipe_kernel.
+template <int PRO, bool WT>
+__global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p, int pool_shift)
+{
+    constexpr int BN = 128, BM = 32;
+    constexpr int LDBT = BN + 4;
+    constexpr int SB_ELEMS = WT ? MLP_BK * LDBT : BN * MLP_LD;
+    constexpr int SA_ELEMS = BM * MLP_LD;
+    __shared__ __attribute__((aligned(16))) float sAbuf[2 * SA_ELEMS];
+    __shared__ __attribute__((aligned(16))) float sBbuf[2 * SB_ELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int col0 = blockIdx.y * BN;
+    const int ntiles = (p.M + BM - 1) / BM;
+    const int nk = (p.K + MLP_BK - 1) / MLP_BK;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nsteps = my_tiles * nk;
+    const bool bwd_epi = p.mask_z != nullptr;
+    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: row ar (0..31), 4 columns at ac4
+
+    float4 ra, rz, rb[4];
+    uchar4 rk;
+    float4 cs, ch, cm, ci, cc1, cc2;
+    ra = rz = cs = ch = cm = ci = cc1 = cc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    rk = make_uchar4(255, 255, 255, 255);
+
+    auto issue = [&](int step) {
+        const int t = step / nk, kc = step - t * nk;
+        const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM, k0 = kc * MLP_BK;
+        const int k = k0 + ac4;
+        const bool kok = k < p.K;
+        const int row = row0 + ar;
+        ra = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRO == PRO_BN_BWD) { rz = ra; rk = make_uchar4(255, 255, 255, 255); }
+        if (row < p.M && kok) {
+            if (PRO == PRO_BN_BWD) {
+                if (p.argk) {
+                    const int cent = pool_shift >= 0 ? (row >> pool_shift) : row / p.pool_k;
+                    ra = *reinterpret_cast<const float4 *>(p.x1 + (size_t)cent * p.ld1 + k);
+                    rk = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.K1 + k);
+                } else {
+                    ra = *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k);
+                }
+                rz = *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + k);
+            } else {
+                ra = k < p.K1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k)
+                              : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k - p.K1));
+            }
+        }
+        if (PRO != PRO_NONE && kok) {
+            cs = *reinterpret_cast<const float4 *>(p.scale + k);
+            ch = *reinterpret_cast<const float4 *>(p.shift + k);
+            if (PRO == PRO_BN_BWD) {
+                cm = *reinterpret_cast<const float4 *>(p.mean + k);
+                ci = *reinterpret_cast<const float4 *>(p.invstd + k);
+                cc1 = *reinterpret_cast<const float4 *>(p.c1 + k);
+                cc2 = *reinterpret_cast<const float4 *>(p.c2 + k);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * MLP_THREADS;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!WT) {
+                const int r = e >> 3, c4 = (e & 7) * 4;
+                if (col0 + r < p.N && k0 + c4 < p.K)
+                    rb[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)(col0 + r) * p.ldw + k0 + c4);
+            } else {
+                const int kk = e / (BN / 4), c4 = (e - kk * (BN / 4)) * 4;
+                if (k0 + kk < p.K && col0 + c4 < p.N)
+                    rb[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)(k0 + kk) * p.ldw + col0 + c4);
+            }
+        }
+    };
+    auto commit = [&](int step) {
+        const int t = step / nk;
+        const int row = ((int)blockIdx.x + t * (int)gridDim.x) * BM + ar;
+        float *sA = sAbuf + (step & 1) * SA_ELEMS;
+        float *sB = sBbuf + (step & 1) * SB_ELEMS;
+        float4 v = ra;
+        if (PRO == PRO_BN_RELU) {
+            v.x = fmaxf(cs.x * v.x + ch.x, 0.f);
+            v.y = fmaxf(cs.y * v.y + ch.y, 0.f);
+            v.z = fmaxf(cs.z * v.z + ch.z, 0.f);
+            v.w = fmaxf(cs.w * v.w + ch.w, 0.f);
+            if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (PRO == PRO_BN_BWD) {
+            float4 g = ra;
+            const float4 z = rz;
+            if (p.argk) {
+                const int kk = pool_shift >= 0 ? (row & ((1 << pool_shift) - 1)) : row % p.pool_k;
+                g.x = rk.x == kk ? g.x : 0.f;
+                g.y = rk.y == kk ? g.y : 0.f;
+                g.z = rk.z == kk ? g.z : 0.f;
+                g.w = rk.w == kk ? g.w : 0.f;
+            }
+#define PN2_DZ(f) v.f = cs.f * (((cs.f * z.f + ch.f) > 0.f ? g.f : 0.f) - cc1.f - (z.f - cm.f) * ci.f * cc2.f)
+            PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+            if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *reinterpret_cast<float4 *>(&sA[ar * MLP_LD + ac4]) = v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * MLP_THREADS;
+            if (!WT) {
+                const int r = e >> 3, c4 = (e & 7) * 4;
+                *reinterpret_cast<float4 *>(&sB[r * MLP_LD + c4]) = rb[i];
+            } else {
+                const int kk = e / (BN / 4), c4 = (e - kk * (BN / 4)) * 4;
+                *reinterpret_cast<float4 *>(&sB[kk * LDBT + c4]) = rb[i];
+            }
+        }
+    };
+
+    float csum = 0.f, csq = 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int col = col0 + wave * 32 + l31;                  // this lane's output column
+
+    if (nsteps > 0) {
+        issue(0);
+        commit(0);
+        __syncthreads();
+    }
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) issue(step + 1);
+        const float *sA = sAbuf + (step & 1) * SA_ELEMS;
+        const float *sB = sBbuf + (step & 1) * SB_ELEMS;
+        const float *aRow = &sA[l31 * MLP_LD + 16 * half];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
+            float4 b4;
+            if (!WT) {
+                b4 = *reinterpret_cast<const float4 *>(&sB[(wave * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
+            } else {
+                const float *bp = &sB[(16 * half + 4 * q) * LDBT + wave * 32 + l31];
+                b4 = make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        const int t = step / nk, kc = step - t * nk;
+        if (kc == nk - 1) {
+            const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM;
+            if (col < p.N) {
+                const float bv = p.bias ? p.bias[col] : 0.f;
+                float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
+                float zp[16];
+                if (bwd_epi) {
+                    ms = p.mscale[col]; mh = p.mshift[col]; mm = p.mmean[col]; mi = p.minvstd[col];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        zp[r] = row < p.M ? p.mask_z[(size_t)row * p.ldm + col] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < p.M) {
+                        float z = acc[r] + bv;
+                        if (bwd_epi) {
+                            z = (ms * zp[r] + mh) > 0.f ? z : 0.f;
+                            csum += z;
+                            csq += z * ((zp[r] - mm) * mi);
+                        } else {
+                            csum += z;
+                            csq += z * z;
+                        }
+                        p.out[(size_t)row * p.ldo + col] = z;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        }
+        if (step + 1 < nsteps) commit(step + 1);
+        __syncthreads();
+    }
+    if (!p.stat_partial) return;
+    const float s = csum + __shfl_xor(csum, 32);
+    const float q = csq + __shfl_xor(csq, 32);
+    if (half == 0 && col < p.N) {                             // every wave owns its own 32 columns
+        p.stat_partial[((size_t)blockIdx.x * 2 + 0) * p.N + col] = s;
+        p.stat_partial[((size_t)blockIdx.x * 2 + 1) * p.N + col] = q;
+    }
+}
+
 // partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
 // :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
 // estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
@@ -943,9 +1140,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// 32-row tiles are used when 128-row tiles would give fewer workgroups than CUs
+static bool pn2_mlp_gemm_uses_rows32(int M, int N)
+{
+    const long long wgs128 = (long long)((M + MLP_BM - 1) / MLP_BM) * ((N + 127) / 128);
+    return wgs128 < pn2::tune_get("mlp_rows32_thresh", 512);
+}
+
 PN2_EXPORT int pn2_mlp_gemm_max_partials(int M)
 {
-    const int ntiles = (M + MLP_BM - 1) / MLP_BM;
+    // upper bound over both tilings (the statistics workspace is sized by the caller from this)
+    const int ntiles = (M + 31) / 32;
     return ntiles < 512 ? (ntiles < 1 ? 1 : ntiles) : 512;
 }
 
@@ -986,6 +1191,22 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
     if (prologue == PRO_BN_BWD) vec4 = vec4 && aligned16(mean) && aligned16(invstd) && aligned16(c1) && aligned16(c2);
     const int gx = pn2_mlp_gemm_max_partials(M);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    {
+        bool pipe_ok = vec4 && (ldw % 4 == 0) && aligned16(w) && (w_is_kn ? (N % 4 == 0) : true);
+        if (prologue == PRO_BN_BWD && argk) pipe_ok = pipe_ok && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
+        // few rows: 32-row tiles so that (row tiles) x (128-column blocks) still covers the 256 CUs
+        if (pipe_ok && pn2_mlp_gemm_uses_rows32(M, N) && pn2::tune_get("mlp_rows32", 1)) {
+            int pool_shift = -1;
+            if (a.argk && (a.pool_k & (a.pool_k - 1)) == 0) { pool_shift = 0; while ((1 << pool_shift) < a.pool_k) ++pool_shift; }
+            dim3 grid((unsigned)gx, (unsigned)((N + 127) / 128));
+#define PN2_R32(P, W) hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W>), grid, dim3(MLP_THREADS), 0, stream, a, pool_shift)
+            if (prologue == PRO_NONE) { if (a.wt) PN2_R32(PRO_NONE, true); else PN2_R32(PRO_NONE, false); }
+            else if (prologue == PRO_BN_RELU) { if (a.wt) PN2_R32(PRO_BN_RELU, true); else PN2_R32(PRO_BN_RELU, false); }
+            else { if (a.wt) PN2_R32(PRO_BN_BWD, true); else PN2_R32(PRO_BN_BWD, false); }
+#undef PN2_R32
+            return PN2_LAUNCH_RC();
+        }
+    }
     // the pipelined kernel also stages the weight tile with float4 loads
     bool pipe = vec4 && (ldw % 4 == 0) && aligned16(w) && (w_is_kn ? (N % 4 == 0) : true) && pn2::tune_get("mlp_pipe", 1);
     if (prologue == PRO_BN_BWD && argk) pipe = pipe && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
