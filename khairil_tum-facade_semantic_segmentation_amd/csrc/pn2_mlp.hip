@@ -1002,6 +1002,158 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
     }
 }
 
+// Wide-layer form of mlp_dw_kernel (N >= 128 and K >= 128, all-float4): a workgroup owns a
+// 128(n) x 128(k) block of dW, each wave a 64 x 64 quarter of it over ALL rows of every 64-row
+// tile (no cross-wave reduction), so a staged element feeds twice as many MFMAs and the dz / act
+// tiles are re-staged only N/128 resp. K/128 times.
+constexpr int DW2_ROWS = 64, DW2_LD = 132;
+
+__global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float sD[DW2_ROWS * DW2_LD];   // dz tile  [64 m][128 n]
+    __shared__ __attribute__((aligned(16))) float sX[DW2_ROWS * DW2_LD];   // act tile [64 m][128 k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wn = wave & 1, wk = wave >> 1;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+    const int Kact = p.K1 + p.K2, Kout = Kact + 1;
+    const int ntiles = (p.M + DW2_ROWS - 1) / DW2_ROWS;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int c4 = (tid & 31) * 4, rb = tid >> 5;           // staging: 4 columns at c4, rows rb + 8*i
+    const int n4 = n0 + c4, k4 = k0 + c4;
+    const bool n_ok = n4 < p.N, k_act = k4 < Kact, from1 = k4 < p.K1;
+    float4 sc, sh, mu, is, a1, a2, asc, ash;
+    sc = sh = mu = is = a1 = a2 = asc = ash = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dbs = sc;
+    if (n_ok) {
+        sc = *reinterpret_cast<const float4 *>(p.scale + n4);
+        sh = *reinterpret_cast<const float4 *>(p.shift + n4);
+        mu = *reinterpret_cast<const float4 *>(p.mean + n4);
+        is = *reinterpret_cast<const float4 *>(p.invstd + n4);
+        a1 = *reinterpret_cast<const float4 *>(p.c1 + n4);
+        a2 = *reinterpret_cast<const float4 *>(p.c2 + n4);
+    }
+    if (k_act && p.ascale) {
+        asc = *reinterpret_cast<const float4 *>(p.ascale + k4);
+        ash = *reinterpret_cast<const float4 *>(p.ashift + k4);
+    }
+    float4 gv[8], zv[8], xv[8];
+    uchar4 av[8];
+    auto issue = [&](int tile) {
+        const int row0 = tile * DW2_ROWS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + rb + 8 * i;
+            const bool rok = row < p.M;
+            gv[i] = zv[i] = xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            av[i] = make_uchar4(255, 255, 255, 255);
+            if (rok && n_ok) {
+                if (p.argk) {
+                    const int cent = row / p.pool_k;
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4);
+                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4);
+                } else {
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4);
+                }
+                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4);
+            }
+            if (rok && k_act)
+                xv[i] = from1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k4)
+                              : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k4 - p.K1));
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    // sub-blocks of this wave that lie inside [N] x [Kact]
+    const int na = min(2, max(0, (p.N - (n0 + wn * 64) + 31) / 32));
+    const int nb = min(2, max(0, (Kact - (k0 + wk * 64) + 31) / 32));
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * DW2_ROWS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = rb + 8 * i;
+            const int row = row0 + r;
+            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), av4 = dv;
+            if (row < p.M) {
+                if (n_ok) {
+                    float4 g = gv[i];
+                    if (p.argk) {
+                        const int kk = row % p.pool_k;
+                        g.x = av[i].x == kk ? g.x : 0.f;
+                        g.y = av[i].y == kk ? g.y : 0.f;
+                        g.z = av[i].z == kk ? g.z : 0.f;
+                        g.w = av[i].w == kk ? g.w : 0.f;
+                    }
+                    const float4 z = zv[i];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                    PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                    dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
+                }
+                if (k_act) {
+                    av4 = xv[i];
+                    if (p.ascale) {
+                        av4.x = fmaxf(asc.x * av4.x + ash.x, 0.f);
+                        av4.y = fmaxf(asc.y * av4.y + ash.y, 0.f);
+                        av4.z = fmaxf(asc.z * av4.z + ash.z, 0.f);
+                        av4.w = fmaxf(asc.w * av4.w + ash.w, 0.f);
+                    }
+                }
+            }
+            *reinterpret_cast<float4 *>(&sD[r * DW2_LD + c4]) = dv;
+            *reinterpret_cast<float4 *>(&sX[r * DW2_LD + c4]) = av4;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        // MFMA: i = n, j = k, reduction over the tile's 64 rows (lane half h takes rows 32h .. 32h+31)
+        const float *dBase = &sD[(32 * half) * DW2_LD + wn * 64 + l31];
+        const float *xBase = &sX[(32 * half) * DW2_LD + wk * 64 + l31];
+        if (na > 0 && nb > 0) {
+#pragma unroll 8
+            for (int t = 0; t < 32; ++t) {
+                const float a0 = dBase[t * DW2_LD], a1v = dBase[t * DW2_LD + 32];
+                const float b0 = xBase[t * DW2_LD], b1 = xBase[t * DW2_LD + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                if (nb > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                if (na > 1) {
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0, acc[1][0], 0, 0, 0);
+                    if (nb > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out = p.partial + (size_t)blockIdx.x * p.N * Kout;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int k = k0 + wk * 64 + b * 32 + l31;
+                if (n < p.N && k < Kact) out[(size_t)n * Kout + k] = acc[a][b][r];
+            }
+    if (blockIdx.z == 0) {
+        // bias gradient: 8 threads (rb = 0..7) hold partial column sums for the same 4 columns
+        float *cs = sX;                                           // [8][128]
+        *reinterpret_cast<float4 *>(&cs[rb * 128 + c4]) = dbs;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += cs[i * 128 + tid];
+            out[(size_t)(n0 + tid) * Kout + Kact] = t;
+        }
+    }
+}
+
 // dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order:
 // 32 elements x 8 partial slices per workgroup, slices combined in order through LDS.
 __global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
@@ -1268,9 +1420,16 @@ PN2_EXPORT int pn2_bn_relu_out(const float *z, long long rows_out, int C, int po
 PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
 {
     // ~1024 workgroups in flight: the M axis is split so that (M slabs) x (64x64 output blocks) ~ 1024
-    const int ntiles = (M + MLP_BM - 1) / MLP_BM;
-    const int blocks = ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK);
+    const bool wide = N >= 128 && K >= 128 && pn2::tune_get("mlp_dw128", 0);
+    const int ntiles = wide ? (M + DW2_ROWS - 1) / DW2_ROWS : (M + MLP_BM - 1) / MLP_BM;
+    const int blocks = wide ? ((N + 127) / 128) * ((K + 127) / 128) : ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK);
     int p = 1024 / (blocks < 1 ? 1 : blocks);
+    // (a cap tying the partial-slab traffic to the layer's input traffic was measured: no gain)
+    const int div = pn2::tune_get("dw_p_div", 0);
+    if (div > 0) {
+        const long long cap = (long long)M * (N + K) / ((long long)div * N * (K + 1));
+        if (p > cap) p = (int)cap;
+    }
     if (p < 8) p = 8;
     if (p > ntiles) p = ntiles;
     return p < 1 ? 1 : p;
@@ -1308,7 +1467,11 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
     if (ascale) vec4 = vec4 && aligned16(ascale) && aligned16(ashift);
     if (argk) vec4 = vec4 && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
-    if (vec4) {
+    if (vec4 && N >= 128 && K >= 128 && pn2::tune_get("mlp_dw128", 0)) {   // measured: no gain over the 64x64 form
+        grid.y = (unsigned)((N + 127) / 128);
+        grid.z = (unsigned)((K + 127) / 128);
+        hipLaunchKernelGGL(mlp_dw128_kernel, grid, dim3(MLP_THREADS), 0, stream, a);
+    } else if (vec4) {
         grid.z = (unsigned)((K + DW_BK - 1) / DW_BK);             // the bias column is summed on the side
         hipLaunchKernelGGL(mlp_dw_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
     } else {
