@@ -15,8 +15,8 @@
 // the sign bit of f is clear (r2 - dist == +0 when equal).  32 centroids x 32 points per MFMA
 // triple; the vector unit only collects 16 sign bits per lane (v_alignbit_b32).
 //
-// Work split: a 512-thread workgroup = 2 centroid groups (32 each) x 4 point quarters; every
-// wave scans its quarter for its 32 centroids and appends hits to a per-(centroid, quarter)
+// Work split: a 1024-thread workgroup = 2 centroid groups (32 each) x 8 point slices; every
+// wave scans its slice for its 32 centroids and appends hits to a per-(centroid, slice)
 // sub-list with LDS atomics; sub-lists are verified ascending (re-ranked if an atomic pair landed
 // out of order), concatenated in quarter order and truncated to nsample, which is exactly "the
 // nsample lowest indices" (:103).  Grouping as in pn2_ball_group.hip.
@@ -28,8 +28,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MF_THREADS = 512;
-constexpr int MF_WAVES = 8;
+constexpr int MF_THREADS = 1024;
+constexpr int MF_WAVES = 16;
+constexpr int MF_SLICES = 8;                  // point slices per centroid group (one wave each)
 constexpr int MF_CENT = 64;                   // centroids per workgroup (2 groups of 32)
 constexpr int MF_MAXN = 4096;                 // whole block resident in LDS as SoA x,y,z,|p|^2
 
@@ -39,16 +40,16 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
     int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NT = (N + 127) & ~127;                              // 4 quarters of a multiple of 32
-    const int NQ = NT >> 2;
+    const int NT = (N + 32 * MF_SLICES - 1) / (32 * MF_SLICES) * (32 * MF_SLICES);   // slices of a multiple of 32
+    const int NQ = NT / MF_SLICES;
     const int cap = K + 32;                                       // sub-list capacity (see header)
     float *sX = reinterpret_cast<float *>(smem);
     float *sY = sX + NT;
     float *sZ = sY + NT;
     float *sP = sZ + NT;                                          // -|p|^2 (-inf on padding)
-    unsigned *cnt = reinterpret_cast<unsigned *>(sP + NT);        // [64][4]
-    int *merged = reinterpret_cast<int *>(cnt + MF_CENT * 4);     // [64][K] ushort merged lists (MF_CENT*K/2 ints)
-    unsigned short *lists = reinterpret_cast<unsigned short *>(merged + MF_CENT * K / 2 + 2);   // [64][4][cap]
+    unsigned *cnt = reinterpret_cast<unsigned *>(sP + NT);        // [64][MF_SLICES]
+    int *merged = reinterpret_cast<int *>(cnt + MF_CENT * MF_SLICES);     // [64][K] ushort merged lists (MF_CENT*K/2 ints)
+    unsigned short *lists = reinterpret_cast<unsigned short *>(merged + MF_CENT * K / 2 + 2);   // [64][MF_SLICES][cap]
 
     const unsigned logical = pn2::xcd_remap(blockIdx.x, gridDim.x);
     const int b = (int)(logical / (unsigned)tiles_per_block);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, quarter = wave & 3;
+    const int grp = wave / MF_SLICES, quarter = wave % MF_SLICES;   // `quarter` = this wave's point slice
     const int s_base = tile * MF_CENT;
 
     const float *bx = xyz + (size_t)b * N * 3;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
 
     // ---- stage the block (all loads of a thread issued first) ----------------------------------
     {
-        constexpr int PT = MF_MAXN / MF_THREADS;
+        constexpr int PT = MF_MAXN / MF_THREADS;          // 4 points per thread
         float sx[PT], sy[PT], sz[PT];
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
                 sP[j] = in ? -pn2::norm3(sx[i], sy[i], sz[i]) : -INFINITY;     // padding: f = -inf, never a hit
             }
         }
-        if (tid < MF_CENT * 4) cnt[tid] = 0;
+        if (tid < MF_CENT * MF_SLICES) cnt[tid] = 0;
     }
 
     // ---- A operands: lane l -> centroid i = l&31 of this wave's group, k = l>>5 -----------------
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
                 const unsigned row = (unsigned)((r & 3) + 8 * (r >> 2) + 4 * half);   // C/D row of register r
                 if (row < rows_valid) {
                     const int c = grp * 32 + (int)row;
-                    const unsigned pos = atomicAdd(&cnt[c * 4 + quarter], 1u);
-                    if (pos < (unsigned)cap) lists[(c * 4 + quarter) * cap + pos] = (unsigned short)j;
+                    const unsigned pos = atomicAdd(&cnt[c * MF_SLICES + quarter], 1u);
+                    if (pos < (unsigned)cap) lists[(c * MF_SLICES + quarter) * cap + pos] = (unsigned short)j;
                 }
             }
         }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
     // ---- (1) every sub-list must be ascending: arrival order is, except that two hits of one
     //      32-point step may have landed swapped.  One thread per (centroid, quarter) checks and,
     //      if needed, insertion-sorts its sub-list (rare, short). ---------------------------------
-    if (tid < MF_CENT * 4) {
+    if (tid < MF_CENT * MF_SLICES) {
         const int nq = (int)min(cnt[tid], (unsigned)cap);
         unsigned short *L = lists + tid * cap;
         bool bad = false;
@@ -181,18 +182,19 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
         const int c = e / K, k = e - c * K;
         const int s = s_base + c;
         if (s >= S) continue;
-        const int n0 = (int)min(cnt[c * 4 + 0], (unsigned)cap), n1 = (int)min(cnt[c * 4 + 1], (unsigned)cap);
-        const int n2 = (int)min(cnt[c * 4 + 2], (unsigned)cap), n3 = (int)min(cnt[c * 4 + 3], (unsigned)cap);
-        const int total = n0 + n1 + n2 + n3;
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < MF_SLICES; ++q) total += (int)min(cnt[c * MF_SLICES + q], (unsigned)cap);
         const int kk = k < total ? k : 0;                       // pad with the first hit
-        int q, off;
-        if (kk < n0) { q = 0; off = kk; }
-        else if (kk < n0 + n1) { q = 1; off = kk - n0; }
-        else if (kk < n0 + n1 + n2) { q = 2; off = kk - n0 - n1; }
-        else { q = 3; off = kk - n0 - n1 - n2; }
+        int q = 0, off = kk;
+#pragma unroll
+        for (int qq = 0; qq < MF_SLICES - 1; ++qq) {            // walk the slices in index order
+            const int nq = (int)min(cnt[c * MF_SLICES + qq], (unsigned)cap);
+            if (q == qq && off >= nq) { off -= nq; q = qq + 1; }
+        }
         int64_t v = N;                                          // reference: IndexError at :59
         unsigned short vs = 0xffff;
-        if (total > 0) { vs = lists[(c * 4 + q) * cap + off]; v = vs; }
+        if (total > 0) { vs = lists[(c * MF_SLICES + q) * cap + off]; v = vs; }
         else if (k == 0 && err_count) atomicAdd(err_count, 1);
         idx[((size_t)b * S + s) * K + k] = v;
         mlist[e] = vs;
@@ -266,10 +268,10 @@ int launch_ball_query_mfma(const float *xyz, const float *new_xyz, const float *
     // the workgroup-wide grouping pass is built for rows of 4*q floats (SA1: 3+9 = 12); other row
     // shapes go through the vector-unit kernel / the element-wise grouping kernel
     if (grouped && !(ldg == 3 + D && ((3 + D) & 3) == 0)) return PN2_ERR_UNSUPPORTED;
-    const int NT = (N + 127) & ~127;
+    const int NT = (N + 32 * MF_SLICES - 1) / (32 * MF_SLICES) * (32 * MF_SLICES);
     const int cap = K + 32;
-    const size_t lds = (size_t)NT * 4 * sizeof(float) + MF_CENT * 4 * sizeof(unsigned) + ((size_t)MF_CENT * K / 2 + 2) * sizeof(int) +
-                       (size_t)MF_CENT * 4 * cap * sizeof(unsigned short);
+    const size_t lds = (size_t)NT * 4 * sizeof(float) + MF_CENT * MF_SLICES * sizeof(unsigned) + ((size_t)MF_CENT * K / 2 + 2) * sizeof(int) +
+                       (size_t)MF_CENT * MF_SLICES * cap * sizeof(unsigned short);
     if (lds > 160 * 1024) return PN2_ERR_UNSUPPORTED;
     const int tiles = (S + MF_CENT - 1) / MF_CENT;
     const long long nwg = (long long)B * tiles;
