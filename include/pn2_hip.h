@@ -120,6 +120,8 @@ int pn2_three_interpolate_backward(const float *grad_out, const int64_t *idx3, c
  *               with argk != NULL, g is the gradient of the max-pooled output [M/pool_k, K1] and
  *               is routed to row argk (autograd of torch.max over nsample, :200).
  * W is [N][K] row-major (w_is_kn = 0) or [K][N] (w_is_kn = 1; the weight itself, for dX = dZ * W).
+ * out2 (nullable): columns >= nsplit are written to out2[M][N-nsplit] (pitch ldo2) instead of out --
+ * the gradient of a two-source input [x1 | x2] lands in two dense tensors without a slicing copy.
  * stat_partial (nullable) [pn2_mlp_gemm_max_partials(M)][2][N]: per-workgroup column sums of out
  * and out^2 (train-mode batch statistics) -- or, when mask_z != NULL (backward), out is first
  * masked by the ReLU of the layer below (mscale*mask_z+mshift > 0) and the sums are those of
@@ -128,8 +130,8 @@ int pn2_mlp_gemm_max_partials(int M);
 int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
                  const float *scale, const float *shift, const float *mean, const float *invstd,
                  const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w,
-                 int ldw, int w_is_kn, const float *bias, float *out, int ldo, int M, int N,
-                 float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
+                 int ldw, int w_is_kn, const float *bias, float *out, int ldo, float *out2, int ldo2, int nsplit,
+                 int M, int N, float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
                  const float *mmean, const float *minvstd, pn2_stream_t stream);
 
 /* partial[P][2][C] -> train-mode BatchNorm coefficients scale = gamma*invstd, shift = beta -

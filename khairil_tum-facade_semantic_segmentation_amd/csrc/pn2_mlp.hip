@@ -47,6 +47,8 @@ struct GemmArgs {
     const float *bias;            // [N] or null
     float *out;                   // [M][N], pitch ldo
     int ldo, M, N, K;
+    float *out2;                  // optional: columns >= nsplit go to out2[M][N-nsplit] (pitch ldo2) instead
+    int ldo2, nsplit;
     float *stat_partial;          // [gridDim.x][2][N] or null: column sums of out and out^2
     // backward epilogue (mask_z != null): out = (mscale*zprev+mshift > 0) ? out : 0 ; partials of
     // sum(out) and sum(out * (zprev-mmean)*minvstd) go to stat_partial instead
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
                     csum[cb] += z;
                     csq[cb] += z * z;
                 }
-                p.out[(size_t)row * p.ldo + col] = z;
+                if (p.out2 && col >= p.nsplit) p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] = z;
+                else p.out[(size_t)row * p.ldo + col] = z;
             }
         }
     }
@@ -447,7 +450,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
                                 csum[cb] += z;
                                 csq[cb] += z * z;
                             }
-                            p.out[(size_t)row * p.ldo + col] = z;
+                            if (p.out2 && col >= p.nsplit) p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] = z;
+                else p.out[(size_t)row * p.ldo + col] = z;
                         }
                     }
                 }
@@ -653,7 +657,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
                             csum += z;
                             csq += z * z;
                         }
-                        p.out[(size_t)row * p.ldo + col] = z;
+                        if (p.out2 && col >= p.nsplit) p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] = z;
+                else p.out[(size_t)row * p.ldo + col] = z;
                     }
                 }
             }
@@ -1310,14 +1315,15 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
                             const float *scale, const float *shift, const float *mean, const float *invstd,
                             const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w, int ldw,
                             int w_is_kn,
-                            const float *bias, float *out, int ldo, int M, int N, float *stat_partial,
-                            const float *mask_z, int ldm, const float *mscale, const float *mshift,
+                            const float *bias, float *out, int ldo, float *out2, int ldo2, int nsplit, int M, int N,
+                            float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
                             const float *mmean, const float *minvstd, pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(x1);
     PN2_REQUIRE_PTR(w);
     PN2_REQUIRE_PTR(out);
-    if (M < 0 || N <= 0 || K1 <= 0 || K2 < 0 || ld1 < K1 || ldo < N) return PN2_ERR_SHAPE;
+    if (M < 0 || N <= 0 || K1 <= 0 || K2 < 0 || ld1 < K1) return PN2_ERR_SHAPE;
+    if (out2 ? (nsplit <= 0 || nsplit >= N || ldo < nsplit || ldo2 < N - nsplit) : (ldo < N)) return PN2_ERR_SHAPE;
     if (prologue < PRO_NONE || prologue > PRO_BN_BWD) return PN2_ERR_SHAPE;
     if (prologue == PRO_BN_BWD) {
         if (!x2 || !scale || !shift || !mean || !invstd || !c1 || !c2) return PN2_ERR_NULL;
@@ -1333,6 +1339,7 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.c1 = c1; a.c2 = c2;
     a.argk = prologue == PRO_BN_BWD ? argk : nullptr; a.pool_k = pool_k;
     a.w = w; a.ldw = ldw; a.wt = w_is_kn; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N;
+    a.out2 = out2; a.ldo2 = ldo2; a.nsplit = nsplit;
     a.K = prologue == PRO_BN_BWD ? K1 : K1 + K2;
     a.stat_partial = stat_partial;
     a.mask_z = mask_z; a.mscale = mscale; a.mshift = mshift; a.mmean = mmean; a.minvstd = minvstd; a.ldm = ldm;

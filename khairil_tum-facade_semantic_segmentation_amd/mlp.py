@@ -29,15 +29,15 @@ def _side_stream(dev):
 
 
 def _gemm(lib, dev, x1, K1, x2, K2, pro, consts, argk, pool_k, w, ldw, w_is_kn, bias, out, M, N, stat=None,
-          mask=None):
+          mask=None, out2=None, nsplit=0):
     """Thin positional wrapper of pn2_mlp_gemm.  consts = (scale, shift, mean, invstd, c1, c2) or None;
     mask = (mask_z, mscale, mshift, mmean, minvstd) or None."""
     c = consts or (None,) * 6
     m = mask or (None,) * 5
     rc = lib.pn2_mlp_gemm(_ptr(x1), x1.stride(0), K1, _ptr(x2), 0 if x2 is None else x2.stride(0), K2, pro,
                           _ptr(c[0]), _ptr(c[1]), _ptr(c[2]), _ptr(c[3]), _ptr(c[4]), _ptr(c[5]),
-                          _ptr(argk), pool_k, _ptr(w), ldw, w_is_kn, _ptr(bias), _ptr(out), out.stride(0), M, N,
-                          _ptr(stat), _ptr(m[0]), 0 if m[0] is None else m[0].stride(0), _ptr(m[1]), _ptr(m[2]),
+                          _ptr(argk), pool_k, _ptr(w), ldw, w_is_kn, _ptr(bias), _ptr(out), out.stride(0),
+                          _ptr(out2), 0 if out2 is None else out2.stride(0), nsplit, M, N, _ptr(stat), _ptr(m[0]), 0 if m[0] is None else m[0].stride(0), _ptr(m[1]), _ptr(m[2]),
                           _ptr(m[3]), _ptr(m[4]), _stream(dev))
     _lib.check(rc, "pn2_mlp_gemm")
 
@@ -194,11 +194,13 @@ class _MLPStack(torch.autograd.Function):
                     need1 = ctx.needs_input_grad[2]
                     need2 = ctx.has_x2 and ctx.needs_input_grad[3]
                     if need1 or need2:
-                        gx = torch.empty((M, Ci), **f32)
+                        # the two halves of the input gradient land in two dense tensors (no slicing copies)
+                        gx1 = torch.empty((M, K1), **f32)
+                        gx2 = torch.empty((M, K2), **f32) if K2 else None
                         _gemm(lib, dev, g, Co, z, Co, PRO_BN_BWD, consts, g_argk, pool_k if g_argk is not None else 0, w2,
-                              w2.stride(0), 1, None, gx, M, Ci)
-                        gx1 = gx[:, :K1] if need1 else None
-                        gx2 = gx[:, K1:] if need2 else None
+                              w2.stride(0), 1, None, gx1, M, Ci, out2=gx2, nsplit=K1 if K2 else 0)
+                        gx1 = gx1 if need1 else None
+                        gx2 = gx2 if need2 else None
             if side is not None:
                 main.wait_stream(side)                  # join: every dW/db is complete before grads are used
         return (None, None, gx1, gx2) + tuple(grads)
