@@ -107,6 +107,43 @@ def test_ball_query_group_ragged_shapes(pn2, orc, B, N, S, K, D):
     pn2.ops.check_errors()
 
 
+@pytest.mark.parametrize("B,N,S,K,D,radius", [(8, 4096, 600, 32, 9, 0.12), (40, 1000, 130, 16, 5, 0.12),
+                                              (70, 777, 65, 64, 1, 0.12), (33, 4000, 127, 32, 0, 0.12),
+                                              (5, 3333, 1000, 7, 13, 0.12), (64, 64, 64, 32, 9, 0.12),
+                                              (7, 4096, 640, 32, 9, 0.5), (9, 2500, 500, 8, 1, 2.0)])
+def test_ball_query_matrix_core_path_ragged(pn2, orc, B, N, S, K, D, radius):
+    """B*S >= 4096 and N <= 4096 take the MFMA kernel (pn2_ball_mfma.hip): ragged S / N / K, dense balls
+    (sub-list overflow + truncation), duplicates, with and without grouping."""
+    rs = np.random.RandomState(B + N + S)
+    xyz = rs.uniform(-0.5, 0.5, size=(B, N, 3)).astype(np.float32)
+    xyz[:, :, 1] *= 0.05                                     # thin slab: many balls exceed K (and K+32) hits
+    xyz[:, N // 3] = xyz[:, 1]                               # duplicated point
+    pick = np.stack([rs.choice(N, S, replace=S > N) for _ in range(B)])
+    new_xyz = orc.index_points(xyz, pick)
+    pts = rs.normal(size=(B, N, D)).astype(np.float32) if D else None
+    want = orc.query_ball_point(radius, K, xyz, new_xyz)     # radius 0.5 / 2.0: hundreds of hits per slice
+    idx_only = pn2.U.query_ball_point(radius, K, dev(pn2, xyz), dev(pn2, new_xyz))
+    assert np.array_equal(host(idx_only), want)
+    idx, grouped = pn2.ops.ball_query_group(radius, K, dev(pn2, xyz), dev(pn2, new_xyz), None if pts is None else dev(pn2, pts))
+    assert np.array_equal(host(idx), want)
+    assert np.array_equal(host(grouped), orc.group_points(xyz, new_xyz, pts, want))
+    idx4, g4 = pn2.ops.ball_query_group(radius, K, dev(pn2, xyz), dev(pn2, new_xyz), None if pts is None else dev(pn2, pts), 4)
+    assert np.array_equal(host(idx4), want)
+    assert np.array_equal(host(g4)[..., :3 + D], orc.group_points(xyz, new_xyz, pts, want))
+    assert (host(g4)[..., 3 + D:] == 0).all()
+    pn2.ops.check_errors()
+
+
+def test_ball_query_matrix_core_path_empty_balls(pn2):
+    xyz = np.zeros((8, 512, 3), np.float32)
+    far = np.full((8, 512, 3), 3.0, np.float32)
+    far[:, ::2] = 0.0                                        # every other centroid sits on the points
+    idx = host(pn2.U.query_ball_point(0.1, 8, dev(pn2, xyz), dev(pn2, far)))
+    assert (idx[:, 1::2] == 512).all() and (idx[:, ::2] == np.arange(8)).all()
+    with pytest.raises(IndexError):
+        pn2.ops.check_errors()
+
+
 @pytest.mark.parametrize("B,N,npoint", [(1, 1, 1), (2, 50, 50), (3, 64, 16), (2, 100, 7), (1, 129, 129), (2, 777, 300),
                                         (1, 2048, 64), (2, 5000, 40), (1, 9001, 33), (1, 20000, 20)])
 def test_fps_ragged_shapes(pn2, orc, B, N, npoint):
