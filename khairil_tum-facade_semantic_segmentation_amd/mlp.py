@@ -89,7 +89,10 @@ class _MLPStack(torch.autograd.Function):
                     rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                                                float(bn.eps), _ptr(scale), _ptr(shift), _stream(dev))
                     _lib.check(rc, "pn2_bn_eval_coeff")
-                    coefs.append((scale, shift, None, None))
+                    # mean / invstd of the frozen statistics: only needed if someone back-propagates
+                    # through an eval-mode stack (BatchNorm is then a fixed affine map)
+                    coefs.append((scale, shift, bn.running_mean.detach().clone(),
+                                  torch.rsqrt(bn.running_var.detach() + bn.eps)))
                 zs.append(z)
             Co = zs[-1].shape[1]
             if pool_k:
@@ -115,9 +118,6 @@ class _MLPStack(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        if not ctx.training:
-            raise NotImplementedError("backward through an eval-mode (running-statistics) BatchNorm stack is not "
-                                      "built; the reference only back-propagates in train mode")
         saved = ctx.saved_tensors
         x1 = saved[0]
         x2 = saved[1] if ctx.has_x2 else None
@@ -157,6 +157,9 @@ class _MLPStack(torch.autograd.Function):
                 rc = lib.pn2_bn_bwd_finalize(_ptr(part), P, Co, float(M), _ptr(dgamma), _ptr(dbeta), _ptr(c1), _ptr(c2),
                                              _stream(dev))
                 _lib.check(rc, "pn2_bn_bwd_finalize")
+                if not ctx.training:                    # frozen statistics: dz = scale * gh, no batch terms
+                    c1.zero_()
+                    c2.zero_()
                 grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
                 consts = (sc, sh, mu, istd, c1, c2)
                 # dW, db

@@ -113,3 +113,34 @@ def test_stack_eval_forward(env, M, K1, K2, widths, pool_k):
     scale = float(yr.abs().max()) + 1e-6
     assert float((y - yr).abs().max()) <= 1e-4 * scale + 1e-5
     assert int(bns[0].num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize("M,K1,K2,widths,pool_k", [CASES[0], CASES[3], CASES[5]])
+def test_stack_eval_backward(env, M, K1, K2, widths, pool_k):
+    """Back-propagation through an eval-mode stack (BatchNorm frozen to its running statistics)."""
+    import copy
+    torch, mlp = env
+    convs, bns = make_stack(torch, K1 + K2, widths, seed=3 * M + 1)
+    rconvs, rbns = copy.deepcopy(convs).cuda().eval(), copy.deepcopy(bns).cuda().eval()
+    convs, bns = convs.cuda().eval(), bns.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(M, K1 + K2, generator=g).cuda()
+    x1 = x[:, :K1].contiguous().requires_grad_(True)
+    x2 = x[:, K1:].contiguous().requires_grad_(True) if K2 else None
+    xr = x.clone().requires_grad_(True)
+    y = mlp.mlp_stack(x1, x2, convs, bns, pool_k)
+    yr = torch_reference(torch, xr, rconvs, rbns, pool_k)
+    go = torch.randn(y.shape, generator=g).cuda()
+    y.backward(go)
+    yr.backward(go)
+    gx = x1.grad if x2 is None else torch.cat([x1.grad, x2.grad], dim=1)
+
+    def close(a, b, what):
+        s = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-3 * s + 1e-5, what
+    close(gx, xr.grad, "dx")
+    for l, (c, rc, b, rb) in enumerate(zip(convs, rconvs, bns, rbns)):
+        close(c.weight.grad, rc.weight.grad, "dW%d" % l)
+        close(c.bias.grad, rc.bias.grad, "db%d" % l)           # a real gradient here: BN no longer removes the mean
+        close(b.weight.grad, rb.weight.grad, "dgamma%d" % l)
+        close(b.bias.grad, rb.bias.grad, "dbeta%d" % l)
