@@ -255,10 +255,17 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
 // (BatchNorm/ReLU prologue or the dz formula) and written to LDS after the barrier.
 // WT: the weight is given [K][N] (dX = dZ * W); its tile is staged k-major and read with
 // ds_read_b32 (lanes along N: conflict-free) instead of being transposed.
-template <int BN, int PRO, bool WT>
-__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs p, int pool_shift)
+// NW = 1: 4 waves, each 32 rows x all BN columns.  NW = 2 (BN = 128): 8 waves, each 32 rows x 64 columns
+// -- twice the waves per CU to cover LDS / barrier latency, half the accumulator registers.
+template <int BN, int PRO, bool WT, int NW>
+__global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel(GemmArgs p, int pool_shift)
 {
+    constexpr int T = MLP_THREADS * NW;
     constexpr int NB = BN / 32;
+    constexpr int NBW = NB / NW;                      // 32-column blocks per wave
+    constexpr int AI = 4 / NW;                        // A float4 per thread per chunk
+    constexpr int BI = (NB + NW - 1) / NW;            // B float4 per thread per chunk
+    static_assert(NB % NW == 0 && 4 % NW == 0, "bad wave split");
     constexpr int LDBT = BN + 4;
     constexpr int SB_ELEMS = WT ? MLP_BK * LDBT : BN * MLP_LD;
     constexpr int SA_ELEMS = MLP_BM * MLP_LD;
@@ -267,16 +274,18 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
     __shared__ float sRed[4][2][BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int rw = wave & 3, cw = wave >> 2;         // row slice / column group of this wave
     const int col0 = blockIdx.y * BN;
     const int ntiles = (p.M + MLP_BM - 1) / MLP_BM;
     const int nk = (p.K + MLP_BK - 1) / MLP_BK;
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int nsteps = my_tiles * nk;
     const bool bwd_epi = p.mask_z != nullptr;
-    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: rows ar + 32*i, 4 columns at ac4
+    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: rows ar + (T/8)*i, 4 columns at ac4
+    constexpr int ARS = T / 8;
 
-    float4 ra[4], rz[4], rb[NB];
-    uchar4 rk[4];
+    float4 ra[AI], rz[AI], rb[BI];
+    uchar4 rk[AI];
     float4 cs, ch, cm, ci, cc1, cc2;
     cs = ch = cm = ci = cc1 = cc2 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -286,8 +295,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
         const int k = k0 + ac4;
         const bool kok = k < p.K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + ar + 32 * i;
+        for (int i = 0; i < AI; ++i) {
+            const int row = row0 + ar + ARS * i;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (PRO == PRO_BN_BWD) { rz[i] = ra[i]; rk[i] = make_uchar4(255, 255, 255, 255); }
             if (row < p.M && kok) {
@@ -317,9 +326,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int e = tid + i * MLP_THREADS;
+        for (int i = 0; i < BI; ++i) {
+            const int e = tid + i * T;
             rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e >= BN * 8) continue;
             if (!WT) {
                 const int r = e >> 3, c4 = (e & 7) * 4;              // [BN cols][32 k]
                 if (col0 + r < p.N && k0 + c4 < p.K)
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
         float *sA = sAbuf + (step & 1) * SA_ELEMS;
         float *sB = sBbuf + (step & 1) * SB_ELEMS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
             float4 v = ra[i];
             if (PRO == PRO_BN_RELU) {
                 v.x = fmaxf(cs.x * v.x + ch.x, 0.f);
@@ -346,13 +356,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
                 v.z = fmaxf(cs.z * v.z + ch.z, 0.f);
                 v.w = fmaxf(cs.w * v.w + ch.w, 0.f);
                 // rows past M / columns past K were loaded as 0 and must stay 0 (shift may be > 0)
-                const int row = row0 + ar + 32 * i;
+                const int row = row0 + ar + ARS * i;
                 if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
             } else if (PRO == PRO_BN_BWD) {
                 float4 g = ra[i];
                 const float4 z = rz[i];
                 if (p.argk) {
-                    const int row = row0 + ar + 32 * i;
+                    const int row = row0 + ar + ARS * i;
                     const int kk = pool_shift >= 0 ? (row & ((1 << pool_shift) - 1)) : row % p.pool_k;
                     g.x = rk[i].x == kk ? g.x : 0.f;
                     g.y = rk[i].y == kk ? g.y : 0.f;
@@ -362,14 +372,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
 #define PN2_DZ(f) v.f = cs.f * (((cs.f * z.f + ch.f) > 0.f ? g.f : 0.f) - cc1.f - (z.f - cm.f) * ci.f * cc2.f)
                 PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
 #undef PN2_DZ
-                const int row = row0 + ar + 32 * i;
+                const int row = row0 + ar + ARS * i;
                 if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4 *>(&sA[(ar + 32 * i) * MLP_LD + ac4]) = v;
+            *reinterpret_cast<float4 *>(&sA[(ar + ARS * i) * MLP_LD + ac4]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int e = tid + i * MLP_THREADS;
+        for (int i = 0; i < BI; ++i) {
+            const int e = tid + i * T;
+            if (e >= BN * 8) continue;
             if (!WT) {
                 const int r = e >> 3, c4 = (e & 7) * 4;
                 *reinterpret_cast<float4 *>(&sB[r * MLP_LD + c4]) = rb[i];
@@ -380,10 +391,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
         }
     };
 
-    float csum[NB], csq[NB];
-    f32x16 acc[NB];
+    float csum[NBW], csq[NBW];
+    f32x16 acc[NBW];
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
+    for (int cb = 0; cb < NBW; ++cb) {
         csum[cb] = 0.0f;
         csq[cb] = 0.0f;
 #pragma unroll
@@ -399,17 +410,17 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
         if (step + 1 < nsteps) issue(step + 1);                  // next step's loads fly under the MFMAs
         const float *sA = sAbuf + (step & 1) * SA_ELEMS;
         const float *sB = sBbuf + (step & 1) * SB_ELEMS;
-        const float *aRow = &sA[(wave * 32 + l31) * MLP_LD + 16 * half];
+        const float *aRow = &sA[(rw * 32 + l31) * MLP_LD + 16 * half];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
+            for (int cb = 0; cb < NBW; ++cb) {
                 float4 b4;
                 if (!WT) {
-                    b4 = *reinterpret_cast<const float4 *>(&sB[(cb * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
+                    b4 = *reinterpret_cast<const float4 *>(&sB[((cw * NBW + cb) * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
                 } else {
-                    const float *bp = &sB[(16 * half + 4 * q) * LDBT + cb * 32 + l31];
+                    const float *bp = &sB[(16 * half + 4 * q) * LDBT + (cw * NBW + cb) * 32 + l31];
                     b4 = make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
                 }
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[cb], 0, 0, 0);
@@ -423,8 +434,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
             // ---- epilogue of this tile: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
             const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM;
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-                const int col = col0 + cb * 32 + l31;
+            for (int cb = 0; cb < NBW; ++cb) {
+                const int col = col0 + (cw * NBW + cb) * 32 + l31;
                 if (col < p.N) {
                     const float bv = p.bias ? p.bias[col] : 0.f;
                     float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
@@ -433,13 +444,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
                         ms = p.mscale[col]; mh = p.mshift[col]; mm = p.mmean[col]; mi = p.minvstd[col];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const int row = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                             zp[r] = row < p.M ? p.mask_z[(size_t)row * p.ldm + col] : 0.f;
                         }
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int row = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         if (row < p.M) {
                             float z = acc[cb][r] + bv;
                             if (bwd_epi) {
@@ -464,13 +475,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_gemm_pipe_kernel(GemmArgs 
     }
     if (!p.stat_partial) return;
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
+    for (int cb = 0; cb < NBW; ++cb) {
         float s = csum[cb] + __shfl_xor(csum[cb], 32);
         float q = csq[cb] + __shfl_xor(csq[cb], 32);
-        if (half == 0) { sRed[wave][0][cb * 32 + l31] = s; sRed[wave][1][cb * 32 + l31] = q; }
+        if (half == 0) { sRed[rw][0][(cw * NBW + cb) * 32 + l31] = s; sRed[rw][1][(cw * NBW + cb) * 32 + l31] = q; }
     }
     __syncthreads();
-    for (int e = tid; e < 2 * BN; e += MLP_THREADS) {
+    for (int e = tid; e < 2 * BN; e += T) {
         const int which = e / BN, c = e - which * BN;
         if (col0 + c < p.N) {
             const float v = (sRed[0][which][c] + sRed[1][which][c]) + (sRed[2][which][c] + sRed[3][which][c]);
@@ -1278,7 +1289,11 @@ int launch_gemm(const GemmArgs &a, int pro, bool vec4, bool pipe, int gx, hipStr
     if (pipe) {
         int pool_shift = -1;
         if (a.argk && (a.pool_k & (a.pool_k - 1)) == 0) { pool_shift = 0; while ((1 << pool_shift) < a.pool_k) ++pool_shift; }
-#define PN2_PIPE(P, W) hipLaunchKernelGGL((mlp_gemm_pipe_kernel<BN, P, W>), grid, dim3(MLP_THREADS), 0, stream, a, pool_shift)
+        constexpr int NWmax = BN == 128 ? 2 : 1;
+        // bit per prologue kind; the BN-backward prologue needs too many registers for the 8-wave form
+        const bool wide = NWmax == 2 && ((pn2::tune_get("mlp_nw2", 3) >> pro) & 1);
+#define PN2_PIPE(P, W) do { if (wide) hipLaunchKernelGGL((mlp_gemm_pipe_kernel<BN, P, W, NWmax>), grid, dim3(MLP_THREADS * NWmax), 0, stream, a, pool_shift); \
+                            else hipLaunchKernelGGL((mlp_gemm_pipe_kernel<BN, P, W, 1>), grid, dim3(MLP_THREADS), 0, stream, a, pool_shift); } while (0)
         if (pro == PRO_NONE) { if (a.wt) PN2_PIPE(PRO_NONE, true); else PN2_PIPE(PRO_NONE, false); }
         else if (pro == PRO_BN_RELU) { if (a.wt) PN2_PIPE(PRO_BN_RELU, true); else PN2_PIPE(PRO_BN_RELU, false); }
         else { if (a.wt) PN2_PIPE(PRO_BN_BWD, true); else PN2_PIPE(PRO_BN_BWD, false); }
