@@ -174,6 +174,28 @@ int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long lon
 int pn2_bn_bwd_finalize(const float *partial, int P, int C, double count, float *dgamma, float *dbeta,
                         float *c1, float *c2, pn2_stream_t stream);
 
+/* ---- segmentation head tail and loss (caller of the hot path) ------------------------
+ * x = conv2(x); x = F.log_softmax(x, dim=1)                   models/pointnet2_sem_seg.py:37-38
+ * logp[M][C] = log_softmax(y[M][K] * w[C][K]^T + bias[C]) per row.  K <= 128, K % 4 == 0, C <= 32. */
+int pn2_head_logits(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K,
+                    int C, pn2_stream_t stream);
+/* autograd of the above: from glogp [M][C] -> gy [M][K] (nullable), dw [C][K], db [C] (nullable).
+ * partial: workspace [pn2_head_logits_partials(M)][C][K+1] floats. */
+int pn2_head_logits_partials(int M);
+int pn2_head_logits_backward(const float *glogp, const float *logp, const float *y, int ldy, const float *w,
+                             float *gy, int ldgy, float *partial, float *dw, float *db, int M, int K, int C,
+                             pn2_stream_t stream);
+/* F.nll_loss(pred, target, weight=weight)  (reduction 'mean')   models/pointnet2_sem_seg.py:48
+ * loss = sum_i -w[t_i] logp[i][t_i] / sum_i w[t_i] over rows with t_i != ignore_index; wsum receives the
+ * denominator for the backward.  weight nullable (= ones).  A target outside [0,C): row skipped,
+ * err_count += 1 (nullable).  partial: workspace [pn2_nll_loss_partials(M)][2] doubles. */
+int pn2_nll_loss_partials(long long M);
+int pn2_nll_loss(const float *logp, const int64_t *target, const float *weight, long long M, int C,
+                 long long ignore_index, double *partial, float *loss, float *wsum, int32_t *err_count,
+                 pn2_stream_t stream);
+int pn2_nll_loss_backward(const float *gloss, const int64_t *target, const float *weight, const float *wsum,
+                          long long M, int C, long long ignore_index, float *glogp, pn2_stream_t stream);
+
 /* ---- whole-scene inference aggregation --------------------------------------
  * add_vote(vote_label_pool, point_idx, pred_label, weight)            localfunctions.py:339-346
  * vote_pool[P][C] int32 += 1 at (point_idx[m], label[m]) for every m < M whose weight is neither 0

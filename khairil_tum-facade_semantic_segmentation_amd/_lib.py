@@ -35,6 +35,12 @@ SIGNATURES = {
     "pn2_bn_bwd_reduce_partials": [_cl],
     "pn2_bn_bwd_reduce": [_vp, _ci, _vp, _ci, _cl, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_bn_bwd_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _vp, _vp, _vp],
+    "pn2_head_logits": [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],
+    "pn2_head_logits_partials": [_ci],
+    "pn2_head_logits_backward": [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],
+    "pn2_nll_loss_partials": [_cl],
+    "pn2_nll_loss": [_vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp, _vp, _vp, _vp],
+    "pn2_nll_loss_backward": [_vp, _vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp],
     "pn2_add_vote": [_vp, _vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp, _vp],
 }
 

@@ -1,0 +1,316 @@
+// Segmentation head tail and loss of pointnet2_sem_seg:
+//   x = conv2(x); x = F.log_softmax(x, dim=1)          reference models/pointnet2_sem_seg.py:37-38
+//   F.nll_loss(pred, target, weight=weight)            reference models/pointnet2_sem_seg.py:48
+// Per-point rows [M][K] (K = 128 features) against a [C][K] weight with C <= 32 classes: far too
+// narrow for the 32-column MFMA tiles of pn2_mlp.hip, and HBM-bound anyway (M*K*4 bytes in, M*C*4
+// out), so these are VALU kernels that stream 64-row tiles through LDS with coalesced float4 rows.
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int HD_THREADS = 256;
+constexpr int HD_ROWS = 64;        // rows per tile
+constexpr int HD_KMAX = 128;       // feature width the kernels are built for
+constexpr int HD_CMAX = 32;        // classes
+constexpr int HD_LDY = HD_KMAX + 4;
+
+// ---- forward -----------------------------------------------------------------------------------------
+// tile -> LDS, thread (row = t & 63, jq = t >> 6) accumulates classes jq, jq+4, ... over k in the
+// order k = 0..K-1 (one fma chain per class), then one thread per row does the log-softmax.
+template <int CQ>   // classes per thread = ceil(C / 4)
+__global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__restrict__ y, int ldy,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ logp, int M, int K, int C)
+{
+    __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
+    __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
+    __shared__ float sL[HD_ROWS][HD_CMAX + 1];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * HD_ROWS;
+    const int k4n = K >> 2;
+    for (int e = tid; e < C * k4n; e += HD_THREADS) {
+        const int j = e / k4n, q = e - j * k4n;
+        *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
+    }
+    for (int e = tid; e < HD_ROWS * k4n; e += HD_THREADS) {
+        const int r = e / k4n, q = e - r * k4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < M) v = *reinterpret_cast<const float4 *>(&y[(size_t)(row0 + r) * ldy + 4 * q]);
+        *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = v;
+    }
+    __syncthreads();
+    const int r = tid & 63, jq = tid >> 6;
+    float acc[CQ];
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) acc[i] = 0.f;
+    for (int q = 0; q < k4n; ++q) {
+        const float4 a = *reinterpret_cast<const float4 *>(&sY[r * HD_LDY + 4 * q]);
+#pragma unroll
+        for (int i = 0; i < CQ; ++i) {
+            const int j = jq + 4 * i;
+            if (j < C) {                                      // uniform per wave
+                const float4 b = *reinterpret_cast<const float4 *>(&sW[j * HD_KMAX + 4 * q]);
+                acc[i] = fmaf(a.x, b.x, acc[i]);
+                acc[i] = fmaf(a.y, b.y, acc[i]);
+                acc[i] = fmaf(a.z, b.z, acc[i]);
+                acc[i] = fmaf(a.w, b.w, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+        const int j = jq + 4 * i;
+        if (j < C) sL[r][j] = acc[i] + (bias ? bias[j] : 0.f);
+    }
+    __syncthreads();
+    if (tid < HD_ROWS && row0 + tid < M) {
+        float mx = sL[tid][0];
+        for (int j = 1; j < C; ++j) mx = fmaxf(mx, sL[tid][j]);
+        float s = 0.f;
+        for (int j = 0; j < C; ++j) s += expf(sL[tid][j] - mx);
+        const float lse = mx + logf(s);
+        float *o = logp + (size_t)(row0 + tid) * C;
+        for (int j = 0; j < C; ++j) o[j] = sL[tid][j] - lse;
+    }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------
+// dz = g - exp(logp) * sum_j g_j ;  gy = dz * W ;  dW += dz^T * y ;  db += sum dz.
+// Workgroups walk tiles grid-stride and keep their dW slab in registers; slabs are summed in
+// fixed order by head_dw_reduce_kernel.
+__global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
+    const float *__restrict__ g, const float *__restrict__ logp, const float *__restrict__ y, int ldy,
+    const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int K, int C)
+{
+    __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
+    __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
+    __shared__ __attribute__((aligned(16))) float sD[HD_ROWS][HD_CMAX];
+    const int tid = threadIdx.x;
+    const int k4n = K >> 2;
+    const int ntiles = (M + HD_ROWS - 1) / HD_ROWS;
+    for (int e = tid; e < HD_CMAX * (HD_KMAX / 4); e += HD_THREADS) {
+        const int j = e / (HD_KMAX / 4), q = e - j * (HD_KMAX / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < C && q < k4n) v = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
+        *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = v;
+    }
+    // dW ownership: k = tid & 127, classes 16*(tid >> 7) .. +15
+    const int wk = tid & 127, wj0 = (tid >> 7) * 16;
+    float dwa[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dwa[i] = 0.f;
+    float dba = 0.f;                                          // tid < HD_CMAX: db of class tid
+    // gy ownership: 4 columns at gk4, rows (tid >> 5) + 8 i
+    const int gk4 = (tid & 31) * 4, gr0 = tid >> 5;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * HD_ROWS;
+        __syncthreads();                                      // previous tile's readers are done (also covers sW)
+        for (int e = tid; e < HD_ROWS * k4n; e += HD_THREADS) {
+            const int r = e / k4n, q = e - r * k4n;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < M) v = *reinterpret_cast<const float4 *>(&y[(size_t)(row0 + r) * ldy + 4 * q]);
+            *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = v;
+        }
+        if (tid < HD_ROWS) {
+            const int row = row0 + tid;
+            float gs = 0.f;
+            if (row < M)
+                for (int j = 0; j < C; ++j) gs += g[(size_t)row * C + j];
+            for (int j = 0; j < HD_CMAX; ++j) {
+                float d = 0.f;
+                if (row < M && j < C) d = g[(size_t)row * C + j] - expf(logp[(size_t)row * C + j]) * gs;
+                sD[tid][j] = d;
+            }
+        }
+        __syncthreads();
+        if (gy && gk4 < K) {
+#pragma unroll
+            for (int i = 0; i < HD_ROWS / 8; ++i) {
+                const int r = gr0 + 8 * i;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < C; ++j) {
+                    const float d = sD[r][j];
+                    const float4 b = *reinterpret_cast<const float4 *>(&sW[j * HD_KMAX + gk4]);
+                    a.x = fmaf(d, b.x, a.x);
+                    a.y = fmaf(d, b.y, a.y);
+                    a.z = fmaf(d, b.z, a.z);
+                    a.w = fmaf(d, b.w, a.w);
+                }
+                if (row0 + r < M) *reinterpret_cast<float4 *>(&gy[(size_t)(row0 + r) * ldgy + gk4]) = a;
+            }
+        }
+        if (wj0 < C) {                                        // uniform per wave
+            for (int r = 0; r < HD_ROWS; ++r) {
+                const float yv = sY[r * HD_LDY + wk];
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const float4 d = *reinterpret_cast<const float4 *>(&sD[r][wj0 + 4 * i4]);
+                    dwa[4 * i4 + 0] = fmaf(d.x, yv, dwa[4 * i4 + 0]);
+                    dwa[4 * i4 + 1] = fmaf(d.y, yv, dwa[4 * i4 + 1]);
+                    dwa[4 * i4 + 2] = fmaf(d.z, yv, dwa[4 * i4 + 2]);
+                    dwa[4 * i4 + 3] = fmaf(d.w, yv, dwa[4 * i4 + 3]);
+                }
+            }
+        }
+        if (tid < HD_CMAX)
+            for (int r = 0; r < HD_ROWS; ++r) dba += sD[r][tid];
+    }
+    // slab [C][K+1] of this workgroup
+    float *slab = partial + (size_t)blockIdx.x * C * (K + 1);
+    if (wk < K) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (wj0 + i < C) slab[(size_t)(wj0 + i) * (K + 1) + wk] = dwa[i];
+    }
+    if (tid < C) slab[(size_t)tid * (K + 1) + K] = dba;
+}
+
+// dw[j][k] / db[j] = sum over slabs, in slab order (one thread per element, double accumulation).
+__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float *__restrict__ partial, int P, int C, int K,
+                                                            float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ double sS[8][33];
+    const int el = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const int n = C * (K + 1);
+    double s = 0.0;
+    if (e < n)
+        for (int i = py; i < P; i += 8) s += (double)partial[(size_t)i * n + e];
+    sS[py][el] = s;
+    __syncthreads();
+    if (py != 0 || e >= n) return;
+    for (int i = 1; i < 8; ++i) s += sS[i][el];
+    const int j = e / (K + 1), k = e - j * (K + 1);
+    if (k < K) dw[(size_t)j * K + k] = (float)s;
+    else if (db) db[j] = (float)s;
+}
+
+// ---- weighted negative log-likelihood ---------------------------------------------------------------------
+// loss = sum_i -w[t_i] * logp[i][t_i] / sum_i w[t_i]   (rows with t_i == ignore_index are skipped,
+// F.nll_loss reduction='mean').  Partials per workgroup in double, combined in order.
+__global__ __launch_bounds__(256) void nll_partial_kernel(const float *__restrict__ logp, const int64_t *__restrict__ target,
+                                                         const float *__restrict__ weight, long long M, int C,
+                                                         long long ignore_index, double *__restrict__ partial,
+                                                         int32_t *__restrict__ err_count)
+{
+    __shared__ double sN[256], sDn[256];
+    double num = 0.0, den = 0.0;
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long long)gridDim.x * 256) {
+        const long long t = target[i];
+        if (t == ignore_index) continue;
+        if (t < 0 || t >= C) { bad = 1; continue; }
+        const float wv = weight ? weight[t] : 1.f;
+        num -= (double)(wv * logp[i * C + t]);
+        den += (double)wv;
+    }
+    if (bad && err_count) atomicAdd(err_count, 1);
+    sN[threadIdx.x] = num;
+    sDn[threadIdx.x] = den;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sN[threadIdx.x] += sN[threadIdx.x + s]; sDn[threadIdx.x] += sDn[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sN[0]; partial[2 * blockIdx.x + 1] = sDn[0]; }
+}
+
+__global__ __launch_bounds__(64) void nll_finalize_kernel(const double *__restrict__ partial, int P, float *__restrict__ loss,
+                                                         float *__restrict__ wsum)
+{
+    if (threadIdx.x != 0) return;
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < P; ++i) { num += partial[2 * i]; den += partial[2 * i + 1]; }
+    *loss = (float)(num / den);                               // 0/0 -> nan, as torch
+    *wsum = (float)den;
+}
+
+__global__ __launch_bounds__(256) void nll_backward_kernel(const float *__restrict__ gloss, const int64_t *__restrict__ target,
+                                                          const float *__restrict__ weight, const float *__restrict__ wsum,
+                                                          long long M, int C, long long ignore_index, float *__restrict__ glogp)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * C) return;
+    const long long i = e / C;
+    const int j = (int)(e - i * C);
+    const long long t = target[i];
+    float v = 0.f;
+    if (t == j && t != ignore_index) v = -(weight ? weight[t] : 1.f) / *wsum * *gloss;
+    glogp[e] = v;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+PN2_EXPORT int pn2_head_logits(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K,
+                               int C, pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(y); PN2_REQUIRE_PTR(w); PN2_REQUIRE_PTR(logp);
+    if (M <= 0 || K <= 0 || C <= 0 || ldy < K) return PN2_ERR_SHAPE;
+    if (K > HD_KMAX || C > HD_CMAX || (K & 3) || (ldy & 3) || !aligned16(y) || !aligned16(w)) return PN2_ERR_UNSUPPORTED;
+    const dim3 grid((M + HD_ROWS - 1) / HD_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+    const int cq = (C + 3) / 4;
+#define PN2_HD(Q) hipLaunchKernelGGL((head_logits_kernel<Q>), grid, dim3(HD_THREADS), 0, s, y, ldy, w, bias, logp, M, K, C)
+    if (cq <= 2) PN2_HD(2); else if (cq <= 4) PN2_HD(4); else PN2_HD(8);
+#undef PN2_HD
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_head_logits_partials(int M)
+{
+    const int tiles = (M + HD_ROWS - 1) / HD_ROWS;
+    return tiles < 1 ? 1 : (tiles > 512 ? 512 : tiles);
+}
+
+PN2_EXPORT int pn2_head_logits_backward(const float *glogp, const float *logp, const float *y, int ldy, const float *w,
+                                        float *gy, int ldgy, float *partial, float *dw, float *db, int M, int K, int C,
+                                        pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(glogp); PN2_REQUIRE_PTR(logp); PN2_REQUIRE_PTR(y); PN2_REQUIRE_PTR(w);
+    PN2_REQUIRE_PTR(partial); PN2_REQUIRE_PTR(dw);
+    if (M <= 0 || K <= 0 || C <= 0 || ldy < K || (gy && ldgy < K)) return PN2_ERR_SHAPE;
+    if (K > HD_KMAX || C > HD_CMAX || (K & 3) || (ldy & 3) || !aligned16(y) || !aligned16(w)) return PN2_ERR_UNSUPPORTED;
+    if (gy && ((ldgy & 3) || !aligned16(gy))) return PN2_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int P = pn2_head_logits_partials(M);
+    hipLaunchKernelGGL(head_logits_backward_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
+                       partial, M, K, C);
+    const int n = C * (K + 1);
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, P, C, K, dw, db);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_nll_loss_partials(long long M)
+{
+    const long long b = (M + 1023) / 1024;
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+PN2_EXPORT int pn2_nll_loss(const float *logp, const int64_t *target, const float *weight, long long M, int C,
+                            long long ignore_index, double *partial, float *loss, float *wsum, int32_t *err_count,
+                            pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(logp); PN2_REQUIRE_PTR(target); PN2_REQUIRE_PTR(partial); PN2_REQUIRE_PTR(loss); PN2_REQUIRE_PTR(wsum);
+    if (M <= 0 || C <= 0) return PN2_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int P = pn2_nll_loss_partials(M);
+    hipLaunchKernelGGL(nll_partial_kernel, dim3(P), dim3(256), 0, s, logp, target, weight, M, C, ignore_index, partial,
+                       err_count);
+    hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(64), 0, s, partial, P, loss, wsum);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_nll_loss_backward(const float *gloss, const int64_t *target, const float *weight, const float *wsum,
+                                     long long M, int C, long long ignore_index, float *glogp, pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(gloss); PN2_REQUIRE_PTR(target); PN2_REQUIRE_PTR(wsum); PN2_REQUIRE_PTR(glogp);
+    if (M <= 0 || C <= 0) return PN2_ERR_SHAPE;
+    const long long n = M * C;
+    hipLaunchKernelGGL(nll_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gloss,
+                       target, weight, wsum, M, C, ignore_index, glogp);
+    return PN2_LAUNCH_RC();
+}

@@ -1,0 +1,108 @@
+"""Tail of the segmentation head and the loss on the HIP kernels of csrc/pn2_head.hip.
+
+  head_logits(y, conv2)  = F.log_softmax(conv2(y))          reference models/pointnet2_sem_seg.py:37-38
+  nll_loss(pred, target, weight)                            reference models/pointnet2_sem_seg.py:44-50
+
+Rows are per-point ([M, K] features -> [M, C] log-probabilities); torch supplies memory and
+autograd bookkeeping only."""
+import torch
+
+from . import _lib
+from .ops import _after_fault_op, _dev, _err_word, _ptr, _stream
+
+IGNORE_INDEX = -100          # F.nll_loss default, which the reference does not override
+
+
+class _HeadLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, w, b):
+        dev = _dev(y, w, b)
+        lib = _lib.load()
+        M, K = y.shape
+        C = w.shape[0]
+        w2 = w.reshape(C, K).contiguous()
+        logp = torch.empty((M, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_head_logits(_ptr(y), y.stride(0), _ptr(w2), _ptr(b), _ptr(logp), M, K, C, _stream(dev))
+        _lib.check(rc, "pn2_head_logits")
+        ctx.save_for_backward(y, w2, logp)
+        ctx.wshape = w.shape
+        ctx.has_bias = b is not None
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        y, w2, logp = ctx.saved_tensors
+        dev = g.device
+        lib = _lib.load()
+        M, K = y.shape
+        C = w2.shape[0]
+        g = g.to(torch.float32).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        gy = torch.empty((M, K), **f32) if ctx.needs_input_grad[0] else None
+        P = lib.pn2_head_logits_partials(M)
+        part = torch.empty((P, C, K + 1), **f32)
+        dw = torch.empty((C, K), **f32)
+        db = torch.empty(C, **f32) if ctx.has_bias else None
+        with torch.cuda.device(dev):
+            rc = lib.pn2_head_logits_backward(_ptr(g), _ptr(logp), _ptr(y), y.stride(0), _ptr(w2), _ptr(gy),
+                                              0 if gy is None else gy.stride(0), _ptr(part), _ptr(dw), _ptr(db), M, K, C,
+                                              _stream(dev))
+        _lib.check(rc, "pn2_head_logits_backward")
+        return gy, dw.view(ctx.wshape), db
+
+
+def head_logits(y, weight, bias):
+    """y [M,K] rows, weight [C,K] or [C,K,1] (a 1x1 Conv1d's), bias [C] or None -> log-probs [M,C]."""
+    _dev(y, weight, bias)
+    y = y.to(torch.float32)
+    if y.stride(-1) != 1:
+        y = y.contiguous()
+    return _HeadLogits.apply(y, weight, bias)
+
+
+class _NLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, target, weight):
+        dev = _dev(logp, target, weight)
+        lib = _lib.load()
+        M, C = logp.shape
+        P = lib.pn2_nll_loss_partials(M)
+        part = torch.empty((P, 2), dtype=torch.float64, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)           # loss, sum of weights
+        with torch.cuda.device(dev):
+            rc = lib.pn2_nll_loss(_ptr(logp), _ptr(target), _ptr(weight), M, C, IGNORE_INDEX, _ptr(part), _ptr(out),
+                                  out.data_ptr() + 4, _ptr(_err_word(dev)), _stream(dev))
+        _lib.check(rc, "pn2_nll_loss")
+        _after_fault_op(dev, "nll_loss")
+        ctx.save_for_backward(target, weight, out)
+        ctx.shape = (M, C)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        target, weight, out = ctx.saved_tensors
+        dev = gl.device
+        lib = _lib.load()
+        M, C = ctx.shape
+        gl = gl.to(torch.float32).contiguous()
+        glogp = torch.empty((M, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_nll_loss_backward(_ptr(gl), _ptr(target), _ptr(weight), out.data_ptr() + 4, M, C, IGNORE_INDEX,
+                                           _ptr(glogp), _stream(dev))
+        _lib.check(rc, "pn2_nll_loss_backward")
+        return glogp, None, None
+
+
+def nll_loss(pred, target, weight=None):
+    """pred [M,C] log-probabilities, target [M] int64, weight [C] or None -> scalar mean loss."""
+    _dev(pred, target, weight)
+    if pred.dim() != 2 or target.dim() != 1 or target.shape[0] != pred.shape[0]:
+        raise ValueError("nll_loss expects pred [M,C] and target [M], got %s and %s" % (tuple(pred.shape), tuple(target.shape)))
+    pred = pred.to(torch.float32).contiguous()
+    target = target.to(torch.int64).contiguous()
+    if weight is not None:
+        if weight.numel() != pred.shape[1]:
+            raise ValueError("weight has %d entries for %d classes" % (weight.numel(), pred.shape[1]))
+        weight = weight.detach().to(torch.float32).contiguous()
+    return _NLL.apply(pred, target, weight)

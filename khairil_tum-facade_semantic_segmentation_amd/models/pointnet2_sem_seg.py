@@ -7,7 +7,8 @@ between levels so no tensor is re-laid-out on the way through the network."""
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import head, ops
+from . import pointnet2_utils as _utils
 from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction
 
 # (npoint, radius, nsample, mlp) per set-abstraction level; reference :9-12
@@ -64,12 +65,20 @@ class get_model(nn.Module):
         for j, (lvl, fp) in enumerate(zip((3, 2, 1, 0), (self.fp4, self.fp3, self.fp2, self.fp1))):
             pre = None if geometry is None else (geometry[8 + 2 * j], geometry[9 + 2 * j])
             up = fp.forward_cl(geo[lvl], geo[lvl + 1], feat[lvl] if lvl else None, up, nn=pre)   # :31-34
-        h = up.permute(0, 2, 1)
-        h = self.drop1(F.relu(self.bn1(self.conv1(h))))  # :36
-        h = F.log_softmax(self.conv2(h), dim=1)          # :37-38
-        return h.permute(0, 2, 1), feat[4].permute(0, 2, 1)
+        if _utils._TORCH_MLP:                            # A/B switch: the head through torch ops
+            h = up.permute(0, 2, 1)
+            h = self.drop1(F.relu(self.bn1(self.conv1(h))))  # :36
+            h = F.log_softmax(self.conv2(h), dim=1)          # :37-38
+            return h.permute(0, 2, 1), feat[4].permute(0, 2, 1)
+        B, N, C = up.shape
+        h = _utils._mlp(up.reshape(B * N, C), None, [self.conv1], [self.bn1])   # conv1 -> bn1 -> relu (:36)
+        h = self.drop1(h)
+        logp = head.head_logits(h, self.conv2.weight, self.conv2.bias)         # conv2 -> log_softmax (:37-38)
+        return logp.view(B, N, -1), feat[4].permute(0, 2, 1)
 
 
 class get_loss(nn.Module):                               # reference :44-50
     def forward(self, pred, target, trans_feat, weight):
-        return F.nll_loss(pred, target, weight=weight)
+        if _utils._TORCH_MLP:
+            return F.nll_loss(pred, target, weight=weight)
+        return head.nll_loss(pred, target, weight)

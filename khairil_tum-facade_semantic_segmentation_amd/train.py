@@ -79,6 +79,8 @@ class SemSegTrainer:
         self.group = group
         self.grads = FlatGradients(model)
         self.class_weight = class_weight
+        from .models.pointnet2_sem_seg import get_loss   # criterion of the reference loop (localfunctions.py:212)
+        self.criterion = get_loss()
         on_gpu = next(model.parameters()).is_cuda
         self.graphs = bool(graphs) and on_gpu
         self.optimizer = torch.optim.Adam(self.grads.params, lr=lr, betas=(0.9, 0.999), eps=1e-8,
@@ -127,8 +129,7 @@ class SemSegTrainer:
     def _forward_backward(self, blocks_cf, target, geometry=None):
         self.grads.zero()
         pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
-        loss = torch.nn.functional.nll_loss(pred.reshape(-1, pred.shape[-1]), target.reshape(-1),
-                                            weight=self.class_weight)
+        loss = self.criterion(pred.reshape(-1, pred.shape[-1]), target.reshape(-1), None, self.class_weight)
         loss.backward()
         return loss.detach()
 

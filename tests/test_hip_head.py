@@ -1,0 +1,91 @@
+"""GPU numerics of the segmentation-head tail and the loss (csrc/pn2_head.hip through the C ABI)
+against a plain PyTorch fp32/fp64 CPU reference of the same ops: log_softmax(conv2(x)) and
+F.nll_loss(pred, target, weight) -- reference models/pointnet2_sem_seg.py:37-38,48."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    from khairil_tum_facade_semantic_segmentation_amd import _lib, head
+    _lib.load()
+    return torch, head
+
+
+@pytest.mark.parametrize("M,K,C", [(4096, 128, 13), (1000, 128, 8), (77, 64, 17), (16 * 4096, 128, 13), (3, 32, 32)])
+def test_head_logits_forward_backward(env, M, K, C):
+    torch, head = env
+    g = torch.Generator().manual_seed(M + K + C)
+    y = torch.randn(M, K, generator=g)
+    w = torch.randn(C, K, 1, generator=g) * 0.2
+    b = torch.randn(C, generator=g) * 0.1
+    up = torch.randn(M, C, generator=g)
+
+    yr, wr, br = (t.double().requires_grad_() for t in (y, w, b))
+    ref = torch.log_softmax(torch.nn.functional.conv1d(yr.t().unsqueeze(0), wr, br)[0].t(), dim=1)
+    (ref * up.double()).sum().backward()
+
+    yd, wd, bd = (t.cuda().requires_grad_() for t in (y, w, b))
+    out = head.head_logits(yd, wd, bd)
+    assert out.shape == (M, C)
+    (out * up.cuda()).sum().backward()
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=0, atol=2e-5)   # log-probs (tolerance: north_star 1e-3)
+    scale = lambda t: float(t.abs().max()) + 1e-12
+    for name, got, want in (("gy", yd.grad, yr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        err = float((got.cpu().double() - want).abs().max()) / scale(want)
+        assert err < 2e-5, (name, err)
+
+
+def test_head_logits_no_input_grad(env):
+    torch, head = env
+    y = torch.randn(300, 128).cuda()
+    conv = torch.nn.Conv1d(128, 13, 1).cuda()
+    out = head.head_logits(y, conv.weight, conv.bias)
+    out[:, 3].sum().backward()
+    ref = torch.log_softmax(conv(y.t().unsqueeze(0))[0].t(), dim=1)
+    assert conv.weight.grad.shape == conv.weight.shape
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,C,weighted", [(65536, 13, True), (1000, 8, False), (5, 3, True)])
+def test_nll_loss(env, M, C, weighted):
+    torch, head = env
+    g = torch.Generator().manual_seed(M)
+    logp = torch.log_softmax(torch.randn(M, C, generator=g), dim=1)
+    t = torch.randint(0, C, (M,), generator=g)
+    if M > 100:
+        t[::17] = -100                                    # ignore_index rows are skipped
+    wt = (torch.rand(C, generator=g) + 0.5) if weighted else None
+
+    lr = logp.double().requires_grad_()
+    ref = torch.nn.functional.nll_loss(lr, t, weight=None if wt is None else wt.double())
+    (ref * 1.7).backward()
+
+    ld = logp.cuda().requires_grad_()
+    out = head.nll_loss(ld, t.cuda(), None if wt is None else wt.cuda())
+    (out * 1.7).backward()
+    assert abs(float(out.detach()) - float(ref.detach())) < 1e-6 * max(1.0, abs(float(ref.detach())))
+    torch.testing.assert_close(ld.grad.cpu().double(), lr.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_nll_loss_bad_target_is_reported(env):
+    torch, head = env
+    from khairil_tum_facade_semantic_segmentation_amd import ops
+    logp = torch.log_softmax(torch.randn(64, 5), dim=1).cuda()
+    t = torch.randint(0, 5, (64,))
+    t[7] = 9
+    head.nll_loss(logp, t.cuda())
+    with pytest.raises(IndexError):
+        ops.check_errors()
+
+
+def test_head_rejects_cpu_tensors(env):
+    torch, head = env
+    with pytest.raises(RuntimeError):
+        head.head_logits(torch.randn(8, 128), torch.randn(13, 128), None)
+    with pytest.raises(RuntimeError):
+        head.nll_loss(torch.randn(8, 13), torch.zeros(8, dtype=torch.int64))
