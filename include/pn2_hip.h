@@ -163,6 +163,20 @@ int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned 
                int K2, const float *ascale, const float *ashift, int M, int N, float *partial, float *dw,
                float *db, pn2_stream_t stream);
 
+/* One-pass backward of a conv/BatchNorm/ReLU layer with N, K <= 128 (N, K % 4 == 0): dz as in prologue 2 of
+ * pn2_mlp_gemm from (g, z, argk/pool_k, constants of this layer); gp[M][K] = dz * w[N][K] (nullable), masked by
+ * the ReLU of the layer below when ascale/ashift/amean/ainvstd are given (x is then that layer's raw z and
+ * stat_partial [P][2][K] receives the column sums of gp and gp*xhat; otherwise x is an activation);
+ * dw[N][K] = dz^T * act(x), db[N] (nullable).  dw_partial: workspace [P][N][K+1] floats with
+ * P = pn2_mlp_bwd_layer_partials(M, N, K) (0: shape not covered -> use pn2_mlp_gemm + pn2_mlp_dw). */
+int pn2_mlp_bwd_layer_partials(int M, int N, int K);
+int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
+                      const float *scale, const float *shift, const float *mean, const float *invstd,
+                      const float *c1, const float *c2, const float *w, int ldw, const float *x, int ldx,
+                      const float *ascale, const float *ashift, const float *amean, const float *ainvstd,
+                      float *gp, int ldgp, float *stat_partial, float *dw_partial, float *dw, float *db,
+                      int M, int N, int K, pn2_stream_t stream);
+
 /* BatchNorm+ReLU backward statistics of the top layer of a stack: partial
  * [pn2_bn_bwd_reduce_partials(rows)][2][C] sums of gh and gh*xh over rows (rows = M, or the
  * M/pool_k pooled rows with argk).  pn2_bn_bwd_finalize turns partials (from here or from the

@@ -20,6 +20,10 @@ namespace pn2 {
 // (read on every call: benchmarks only, never set in production).
 int tune_get(const char *name, int dflt);
 
+// dW[n][k] = sum_p partial[p][n][k], db[n] = sum_p partial[p][n][K] over P slabs [N][K+1], fixed order
+// (pn2_mlp.hip); shared by the weight-gradient launchers.
+int launch_dw_reduce(const float *partial, int P, int N, int K, float *dw, float *db, hipStream_t stream);
+
 // |p|^2 exactly as torch.sum(p ** 2, -1) evaluates it: ((x*x + y*y) + z*z), every op rounded
 // (reference models/pointnet2_utils.py:38-39; rule SURVEY.md 8a-2).
 __device__ __forceinline__ float norm3(float x, float y, float z)

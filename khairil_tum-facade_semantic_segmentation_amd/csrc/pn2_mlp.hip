@@ -1457,6 +1457,13 @@ PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
     return p < 1 ? 1 : p;
 }
 
+int pn2::launch_dw_reduce(const float *partial, int P, int N, int K, float *dw, float *db, hipStream_t stream)
+{
+    const int total = N * (K + 1);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(1024), 0, stream, partial, P, N, K, dw, db);
+    return PN2_LAUNCH_RC();
+}
+
 PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
                           const float *scale, const float *shift, const float *mean, const float *invstd,
                           const float *c1, const float *c2, const float *x1, int ld1, int K1, const float *x2,

@@ -1,0 +1,372 @@
+// One-pass backward of a [Conv 1x1 -> BatchNorm -> ReLU] layer for N, K <= 128:
+//   dz   = BatchNorm/ReLU backward of this layer from (g, z)            (prologue 2 of pn2_mlp_gemm)
+//   dX   = dz * W, masked by the ReLU of the layer below, + its BatchNorm-backward column sums
+//   dW  += dz^T * act(x),  db += column sums of dz
+// The two-kernel path (pn2_mlp_gemm prologue 2 + pn2_mlp_dw) reads g and z twice and the layer input
+// twice; these layers are HBM-bound (M up to 524288 rows of 32..128 floats), so this kernel stages
+// every 64-row tile ONCE into LDS and feeds both products from it.  Workgroups are persistent
+// (grid-stride over tiles): W lives in LDS, the dW block and the column sums live in registers until
+// the end, where each workgroup writes one partial slab (summed in fixed order afterwards).
+// autograd of reference models/pointnet2_utils.py:196-200, :312-314.
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FB_THREADS = 512, FB_WAVES = 8, FB_ROWS = 64;
+
+struct BwdArgs {
+    const float *g, *z;                 // g [M][N] (or pooled [M/pool_k][N]), z [M][N]
+    int ldg, ldz;
+    const float *scale, *shift, *mean, *invstd, *c1, *c2;   // this layer (N channels)
+    const unsigned char *argk;
+    int pool_k;
+    const float *w;                     // [N][K]
+    int ldw;
+    const float *x;                     // layer input [M][K]: raw z of the layer below, or an activation
+    int ldx;
+    const float *ascale, *ashift, *amean, *ainvstd;          // layer below (null: x is an activation)
+    float *gp;                          // [M][K] dX (nullable)
+    int ldgp;
+    float *stat_partial;                // [grid][2][K] (nullable)
+    float *dw_partial;                  // [grid][N][K+1]
+    int M, N, K;
+};
+
+template <int NBLK, int KBLK>
+__global__ __launch_bounds__(FB_THREADS) void mlp_bwd_fused_kernel(BwdArgs p)
+{
+    constexpr int NP = 32 * NBLK, KP = 32 * KBLK;
+    constexpr int LDD = NP + 4, LDZ = KP + 4;
+    constexpr int NDX = 2 * KBLK, NDW = NBLK * KBLK;
+    constexpr int DXPW = (NDX + FB_WAVES - 1) / FB_WAVES, DWPW = (NDW + FB_WAVES - 1) / FB_WAVES;
+    constexpr int DROWS = FB_THREADS / (NP / 4);      // rows staged per pass of the dz tile (x NBLK passes = 64)
+    constexpr int XROWS = FB_THREADS / (KP / 4);
+    constexpr int RED = (4 * KP > DROWS * NP) ? 4 * KP : DROWS * NP;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sD = smem;                                 // [64][LDD]  dz tile
+    float *sZ = sD + FB_ROWS * LDD;                   // [64][LDZ]  raw layer input tile
+    float *sW = sZ + FB_ROWS * LDZ;                   // [NP][KP]   weights, zero outside [N][K]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (p.M + FB_ROWS - 1) / FB_ROWS;
+    const bool masked = p.ascale != nullptr;
+
+    for (int e = tid; e < NP * (KP / 4); e += FB_THREADS) {
+        const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.N && k4 < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k4);
+        *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = v;
+    }
+
+    // staging ownership: dz columns dc4..dc4+3, rows dr + DROWS*i; input columns xc4.., rows xr + XROWS*i
+    const int dc4 = (tid % (NP / 4)) * 4, dr = tid / (NP / 4);
+    const int xc4 = (tid % (KP / 4)) * 4, xr = tid / (KP / 4);
+    const bool n_ok = dc4 < p.N, k_ok = xc4 < p.K;
+    float4 sc, sh, mu, is, a1, a2;
+    sc = sh = mu = is = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dbs = sc;
+    if (n_ok) {
+        sc = *reinterpret_cast<const float4 *>(p.scale + dc4);
+        sh = *reinterpret_cast<const float4 *>(p.shift + dc4);
+        mu = *reinterpret_cast<const float4 *>(p.mean + dc4);
+        is = *reinterpret_cast<const float4 *>(p.invstd + dc4);
+        a1 = *reinterpret_cast<const float4 *>(p.c1 + dc4);
+        a2 = *reinterpret_cast<const float4 *>(p.c2 + dc4);
+    }
+
+    // MFMA block ownership.  dX blocks (rb, cb): wave + 8 i.  dW blocks (nb, kb): from the last wave down.
+    float xsc[DXPW], xsh[DXPW], xmu[DXPW], xis[DXPW], csum[DXPW], csq[DXPW];
+#pragma unroll
+    for (int i = 0; i < DXPW; ++i) {
+        const int b = wave + FB_WAVES * i;
+        const int col = (b % KBLK) * 32 + l31;
+        xsc[i] = xsh[i] = xmu[i] = xis[i] = csum[i] = csq[i] = 0.f;
+        if (masked && b < NDX && col < p.K) {
+            xsc[i] = p.ascale[col]; xsh[i] = p.ashift[col]; xmu[i] = p.amean[col]; xis[i] = p.ainvstd[col];
+        }
+    }
+    float wsc[DWPW], wsh[DWPW];
+    f32x16 accW[DWPW];
+#pragma unroll
+    for (int i = 0; i < DWPW; ++i) {
+        const int b = (FB_WAVES - 1 - wave) + FB_WAVES * i;
+        const int col = (b % KBLK) * 32 + l31;
+        wsc[i] = wsh[i] = 0.f;
+        if (masked && b < NDW && col < p.K) { wsc[i] = p.ascale[col]; wsh[i] = p.ashift[col]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[i][r] = 0.f;
+    }
+
+    float4 gv[NBLK], zv[NBLK], xv[KBLK];
+    uchar4 av[NBLK];
+    auto issue = [&](int tile) {
+        const int row0 = tile * FB_ROWS;
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int row = row0 + dr + DROWS * i;
+            gv[i] = zv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            av[i] = make_uchar4(255, 255, 255, 255);
+            if (row < p.M && n_ok) {
+                if (p.argk) {
+                    const int cent = row / p.pool_k;
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + dc4);
+                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + dc4);
+                } else {
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + dc4);
+                }
+                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + dc4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KBLK; ++i) {
+            const int row = row0 + xr + XROWS * i;
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.M && k_ok) xv[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.ldx + xc4);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * FB_ROWS;
+        __syncthreads();                              // readers of the previous tile are done (first pass: sW written)
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int r = dr + DROWS * i;
+            const int row = row0 + r;
+            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.M && n_ok) {
+                float4 g = gv[i];
+                if (p.argk) {
+                    const int kk = row % p.pool_k;
+                    g.x = av[i].x == kk ? g.x : 0.f;
+                    g.y = av[i].y == kk ? g.y : 0.f;
+                    g.z = av[i].z == kk ? g.z : 0.f;
+                    g.w = av[i].w == kk ? g.w : 0.f;
+                }
+                const float4 z = zv[i];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
+            }
+            *reinterpret_cast<float4 *>(&sD[r * LDD + dc4]) = dv;
+        }
+#pragma unroll
+        for (int i = 0; i < KBLK; ++i)
+            *reinterpret_cast<float4 *>(&sZ[(xr + XROWS * i) * LDZ + xc4]) = xv[i];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+
+        // ---- dX = dz * W : lane half h reduces n in [h NP/2, (h+1) NP/2)
+        if (p.gp) {
+#pragma unroll
+            for (int i = 0; i < DXPW; ++i) {
+                const int b = wave + FB_WAVES * i;
+                if (b < NDX) {                        // uniform per wave
+                    const int rb = b / KBLK, cb = b - rb * KBLK;
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    const float *aRow = &sD[(rb * 32 + l31) * LDD + half * (NP / 2)];
+                    const float *bCol = &sW[(half * (NP / 2)) * KP + cb * 32 + l31];
+#pragma unroll
+                    for (int q = 0; q < NP / 8; ++q) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
+                        const float b0 = bCol[(4 * q + 0) * KP], b1 = bCol[(4 * q + 1) * KP];
+                        const float b2 = bCol[(4 * q + 2) * KP], b3 = bCol[(4 * q + 3) * KP];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+                    }
+                    const int col = cb * 32 + l31;
+                    float cs = 0.f, cq = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float v = acc[r];
+                        if (masked) {
+                            const float zp = sZ[rl * LDZ + col];
+                            v = (xsc[i] * zp + xsh[i]) > 0.f ? v : 0.f;
+                            cs += v;
+                            cq += v * ((zp - xmu[i]) * xis[i]);
+                        }
+                        if (row0 + rl < p.M && col < p.K) p.gp[(size_t)(row0 + rl) * p.ldgp + col] = v;
+                    }
+                    csum[i] += cs;
+                    csq[i] += cq;
+                }
+            }
+        }
+        // ---- dW += dz^T * act(x) : reduction over the tile's rows, lane half h takes rows 32h .. 32h+31
+#pragma unroll
+        for (int i = 0; i < DWPW; ++i) {
+            const int b = (FB_WAVES - 1 - wave) + FB_WAVES * i;
+            if (b < NDW) {
+                const int nb = b / KBLK, kb = b - nb * KBLK;
+                const float *dBase = &sD[(32 * half) * LDD + nb * 32 + l31];
+                const float *xBase = &sZ[(32 * half) * LDZ + kb * 32 + l31];
+#pragma unroll 8
+                for (int t = 0; t < 32; ++t) {
+                    const float a = dBase[t * LDD];
+                    float x = xBase[t * LDZ];
+                    if (masked) x = fmaxf(wsc[i] * x + wsh[i], 0.f);
+                    accW[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, accW[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- per-workgroup partials
+    const int Kout = p.K + 1;
+    float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout;
+#pragma unroll
+    for (int i = 0; i < DWPW; ++i) {
+        const int b = (FB_WAVES - 1 - wave) + FB_WAVES * i;
+        if (b < NDW) {
+            const int nb = b / KBLK, kb = b - nb * KBLK;
+            const int k = kb * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < p.N && k < p.K) slab[(size_t)n * Kout + k] = accW[i][r];
+            }
+        }
+    }
+    __syncthreads();
+    float *red = smem;                                // reuse the tile area: max(DROWS*NP, 4*KP) floats
+    static_assert(RED <= FB_ROWS * (NP + 4) + FB_ROWS * (KP + 4), "reduction scratch does not fit");
+    *reinterpret_cast<float4 *>(&red[dr * NP + dc4]) = dbs;
+    __syncthreads();
+    if (tid < p.N) {
+        float t = 0.f;
+        for (int i = 0; i < DROWS; ++i) t += red[i * NP + tid];
+        slab[(size_t)tid * Kout + p.K] = t;
+    }
+    if (p.stat_partial) {
+        __syncthreads();
+        // dX block b = rb*KBLK + cb lives on wave b % 8, slot b / 8: combine rb = 0, 1 per column
+#pragma unroll
+        for (int i = 0; i < DXPW; ++i) {
+            const int b = wave + FB_WAVES * i;
+            if (b < NDX) {
+                const int rb = b / KBLK, cb = b - rb * KBLK;
+                float s = csum[i] + __shfl_xor(csum[i], 32);
+                float q = csq[i] + __shfl_xor(csq[i], 32);
+                if (half == 0) { red[(rb * 2 + 0) * KP + cb * 32 + l31] = s; red[(rb * 2 + 1) * KP + cb * 32 + l31] = q; }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * p.K; e += FB_THREADS) {
+            const int which = e / p.K, c = e - which * p.K;
+            p.stat_partial[((size_t)blockIdx.x * 2 + which) * p.K + c] = red[(0 * 2 + which) * KP + c] + red[(1 * 2 + which) * KP + c];
+        }
+    }
+}
+
+template <int NBLK, int KBLK>
+constexpr int fb_lds_bytes() { return (FB_ROWS * (32 * NBLK + 4) + FB_ROWS * (32 * KBLK + 4) + 32 * NBLK * 32 * KBLK) * 4; }
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int fb_blocks(int n) { return n <= 32 ? 1 : (n <= 64 ? 2 : 4); }
+
+// Resident workgroups per CU of one instantiation (registers and LDS both count), asked of the runtime
+// once; also raises the dynamic-LDS limit of the kernel (> 64 KB has to be requested).
+template <int NBLK, int KBLK>
+int fb_resident()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    constexpr int lds = fb_lds_bytes<NBLK, KBLK>();
+    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_fused_kernel<NBLK, KBLK>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_fused_kernel<NBLK, KBLK>, FB_THREADS, lds) != hipSuccess) return 0;
+    cached = n < 1 ? 0 : (n > 4 ? 4 : n);
+    return cached;
+}
+
+int fb_resident_rt(int nblk, int kblk)
+{
+#define PN2_FB(NB, KB) if (nblk == NB && kblk == KB) return fb_resident<NB, KB>()
+    PN2_FB(1, 1); PN2_FB(1, 2); PN2_FB(1, 4);
+    PN2_FB(2, 1); PN2_FB(2, 2); PN2_FB(2, 4);
+    PN2_FB(4, 1); PN2_FB(4, 2); PN2_FB(4, 4);
+#undef PN2_FB
+    return 0;
+}
+
+template <int NBLK, int KBLK>
+int fb_launch(const BwdArgs &a, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((mlp_bwd_fused_kernel<NBLK, KBLK>), dim3(grid), dim3(FB_THREADS), (fb_lds_bytes<NBLK, KBLK>()), stream, a);
+    return PN2_LAUNCH_RC();
+}
+
+}  // namespace
+
+// Number of partial slabs (= workgroups) pn2_mlp_bwd_layer uses, 0 if the shape is not covered.
+PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || N > 128 || K > 128 || (N & 3) || (K & 3)) return 0;
+    int per_cu = fb_resident_rt(fb_blocks(N), fb_blocks(K));
+    if (per_cu < 1) return 0;
+    int cus = 256;
+    {
+        static int cached_cus = 0;
+        if (!cached_cus) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+                cached_cus = n;
+            else
+                cached_cus = 256;
+        }
+        cus = cached_cus;
+    }
+    const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
+    const int wgs = cus * pn2::tune_get("mlp_fb_wgs", per_cu);
+    return tiles < wgs ? tiles : wgs;
+}
+
+PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
+                                 const float *scale, const float *shift, const float *mean, const float *invstd,
+                                 const float *c1, const float *c2, const float *w, int ldw, const float *x, int ldx,
+                                 const float *ascale, const float *ashift, const float *amean, const float *ainvstd,
+                                 float *gp, int ldgp, float *stat_partial, float *dw_partial, float *dw, float *db,
+                                 int M, int N, int K, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(g); PN2_REQUIRE_PTR(z); PN2_REQUIRE_PTR(scale); PN2_REQUIRE_PTR(shift); PN2_REQUIRE_PTR(mean);
+    PN2_REQUIRE_PTR(invstd); PN2_REQUIRE_PTR(c1); PN2_REQUIRE_PTR(c2); PN2_REQUIRE_PTR(w); PN2_REQUIRE_PTR(x);
+    PN2_REQUIRE_PTR(dw_partial); PN2_REQUIRE_PTR(dw);
+    if (M <= 0 || N <= 0 || K <= 0 || (argk && pool_k <= 0) || ldw < K || ldx < K || ldz < N) return PN2_ERR_SHAPE;
+    const bool masked = ascale != nullptr;
+    if (masked && (!ashift || !amean || !ainvstd)) return PN2_ERR_NULL;
+    if (stat_partial && (!masked || !gp)) return PN2_ERR_NULL;
+    const int P = pn2_mlp_bwd_layer_partials(M, N, K);
+    if (P == 0) return PN2_ERR_UNSUPPORTED;
+    bool ok = (ldg % 4 == 0) && (ldz % 4 == 0) && (ldw % 4 == 0) && (ldx % 4 == 0) && aligned16(g) && aligned16(z) &&
+              aligned16(w) && aligned16(x) && aligned16(scale) && aligned16(shift) && aligned16(mean) &&
+              aligned16(invstd) && aligned16(c1) && aligned16(c2);
+    if (argk) ok = ok && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
+    if (!ok) return PN2_ERR_UNSUPPORTED;
+    BwdArgs a;
+    a.g = g; a.z = z; a.ldg = ldg; a.ldz = ldz; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+    a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.w = w; a.ldw = ldw; a.x = x; a.ldx = ldx;
+    a.ascale = ascale; a.ashift = ashift; a.amean = amean; a.ainvstd = ainvstd; a.gp = gp; a.ldgp = ldgp;
+    a.stat_partial = stat_partial; a.dw_partial = dw_partial; a.M = M; a.N = N; a.K = K;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int nblk = fb_blocks(N), kblk = fb_blocks(K);
+    int rc = PN2_ERR_UNSUPPORTED;
+#define PN2_FB(NB, KB) if (nblk == NB && kblk == KB) rc = fb_launch<NB, KB>(a, P, stream)
+    PN2_FB(1, 1); PN2_FB(1, 2); PN2_FB(1, 4);
+    PN2_FB(2, 1); PN2_FB(2, 2); PN2_FB(2, 4);
+    PN2_FB(4, 1); PN2_FB(4, 2); PN2_FB(4, 4);
+#undef PN2_FB
+    if (rc != PN2_OK) return rc;
+    return pn2::launch_dw_reduce(dw_partial, P, N, K, dw, db, stream);
+}

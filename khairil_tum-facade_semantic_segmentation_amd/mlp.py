@@ -18,6 +18,10 @@ PRO_NONE, PRO_BN_RELU, PRO_BN_BWD = 0, 1, 2
 # fill idle CUs.  Measured on MI355X: 5.06 ms/step with it against 4.81 without (the two kernel
 # families thrash each other), so it is OFF by default; PN2_DW_SIDE_STREAM=1 enables it.
 _DW_SIDE = os.environ.get("PN2_DW_SIDE_STREAM", "0") == "1"
+# Layers with at most 128 input and output channels run their whole backward (dX, dW, db, statistics for
+# the layer below) in one pass over the activations (pn2_mlp_bwd_layer); PN2_FUSED_BWD=0 keeps the
+# two-kernel path (pn2_mlp_gemm prologue 2 + pn2_mlp_dw) for A/B runs.
+_FUSED_BWD = os.environ.get("PN2_FUSED_BWD", "1") == "1"
 _side_streams = {}
 
 
@@ -162,6 +166,33 @@ class _MLPStack(torch.autograd.Function):
                     c2.zero_()
                 grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
                 consts = (sc, sh, mu, istd, c1, c2)
+                Pf = 0
+                if _FUSED_BWD and side is None and (l > 0 or x2 is None):
+                    Pf = lib.pn2_mlp_bwd_layer_partials(M, Co, Ci)
+                if Pf:
+                    pk = pool_k if g_argk is not None else 0
+                    wpart = torch.empty((Pf, Co, Ci + 1), **f32)
+                    dw, db = torch.empty((Co, Ci), **f32), torch.empty(Co, **f32)
+                    if l > 0:
+                        xin, below = zs[l - 1], coefs[l - 1]
+                        gp = torch.empty((M, Ci), **f32)
+                        spart = torch.empty((Pf, 2, Ci), **f32)
+                    else:
+                        xin, below = x1, (None, None, None, None)
+                        gp = torch.empty((M, Ci), **f32) if ctx.needs_input_grad[2] else None
+                        spart = None
+                    rc = lib.pn2_mlp_bwd_layer(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(g_argk), pk, _ptr(sc), _ptr(sh),
+                                               _ptr(mu), _ptr(istd), _ptr(c1), _ptr(c2), _ptr(w2), w2.stride(0), _ptr(xin),
+                                               xin.stride(0), _ptr(below[0]), _ptr(below[1]), _ptr(below[2]), _ptr(below[3]),
+                                               _ptr(gp), 0 if gp is None else gp.stride(0), _ptr(spart), _ptr(wpart), _ptr(dw),
+                                               _ptr(db), M, Co, Ci, _stream(dev))
+                    _lib.check(rc, "pn2_mlp_bwd_layer")
+                    grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db
+                    if l > 0:
+                        g, g_argk, part, P = gp, None, spart, Pf
+                    else:
+                        gx1, gx2 = gp, None
+                    continue
                 # dW, db
                 Pw = lib.pn2_mlp_dw_partials(M, Co, Ci)
                 wpart = torch.empty((Pw, Co, Ci + 1), **f32)
