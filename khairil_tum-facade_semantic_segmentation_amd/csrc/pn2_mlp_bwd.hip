@@ -32,10 +32,11 @@ struct BwdArgs {
     float *stat_partial;                // [grid][2][K] (nullable)
     float *dw_partial;                  // [grid][N][K+1]
     int M, N, K;
+    int dbg;                            // developer switch (PN2_TUNE_FB_DBG): 1 skip dX MFMAs, 2 skip dW MFMAs
 };
 
-template <int NBLK, int KBLK>
-__global__ __launch_bounds__(FB_THREADS) void mlp_bwd_fused_kernel(BwdArgs p)
+template <int NBLK, int KBLK, bool POOLED>
+__global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bwd_fused_kernel(BwdArgs p)
 {
     constexpr int NP = 32 * NBLK, KP = 32 * KBLK;
     constexpr int LDD = NP + 4, LDZ = KP + 4;
@@ -102,29 +103,27 @@ __global__ __launch_bounds__(FB_THREADS) void mlp_bwd_fused_kernel(BwdArgs p)
 
     float4 gv[NBLK], zv[NBLK], xv[KBLK];
     uchar4 av[NBLK];
+    // Loads are unconditional (clamped addresses, masked when consumed): a load under a divergent
+    // branch makes the compiler wait for it at the end of the branch, which serialises the passes.
+    const int dcc = n_ok ? dc4 : 0, xcc = k_ok ? xc4 : 0;
     auto issue = [&](int tile) {
         const int row0 = tile * FB_ROWS;
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) {
-            const int row = row0 + dr + DROWS * i;
-            gv[i] = zv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            av[i] = make_uchar4(255, 255, 255, 255);
-            if (row < p.M && n_ok) {
-                if (p.argk) {
-                    const int cent = row / p.pool_k;
-                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + dc4);
-                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + dc4);
-                } else {
-                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + dc4);
-                }
-                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + dc4);
+            const int row = min(row0 + dr + DROWS * i, p.M - 1);
+            if (POOLED) {                             // g / argk are per centroid
+                const int cent = row / p.pool_k;
+                gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + dcc);
+                av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + dcc);
+            } else {
+                gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + dcc);
             }
+            zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + dcc);
         }
 #pragma unroll
         for (int i = 0; i < KBLK; ++i) {
-            const int row = row0 + xr + XROWS * i;
-            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < p.M && k_ok) xv[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.ldx + xc4);
+            const int row = min(row0 + xr + XROWS * i, p.M - 1);
+            xv[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.ldx + xcc);
         }
     };
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(FB_THREADS) void mlp_bwd_fused_kernel(BwdArgs p)
             float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < p.M && n_ok) {
                 float4 g = gv[i];
-                if (p.argk) {
+                if (POOLED) {
                     const int kk = row % p.pool_k;
                     g.x = av[i].x == kk ? g.x : 0.f;
                     g.y = av[i].y == kk ? g.y : 0.f;
@@ -155,13 +154,15 @@ __global__ __launch_bounds__(FB_THREADS) void mlp_bwd_fused_kernel(BwdArgs p)
             *reinterpret_cast<float4 *>(&sD[r * LDD + dc4]) = dv;
         }
 #pragma unroll
-        for (int i = 0; i < KBLK; ++i)
-            *reinterpret_cast<float4 *>(&sZ[(xr + XROWS * i) * LDZ + xc4]) = xv[i];
+        for (int i = 0; i < KBLK; ++i) {
+            const bool ok = k_ok && row0 + xr + XROWS * i < p.M;
+            *reinterpret_cast<float4 *>(&sZ[(xr + XROWS * i) * LDZ + xc4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 
         // ---- dX = dz * W : lane half h reduces n in [h NP/2, (h+1) NP/2)
-        if (p.gp) {
+        if (p.gp && !(p.dbg & 1)) {
 #pragma unroll
             for (int i = 0; i < DXPW; ++i) {
                 const int b = wave + FB_WAVES * i;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(FB_THREADS) void mlp_bwd_fused_kernel(BwdArgs p)
 #pragma unroll
         for (int i = 0; i < DWPW; ++i) {
             const int b = (FB_WAVES - 1 - wave) + FB_WAVES * i;
-            if (b < NDW) {
+            if (b < NDW && !(p.dbg & 2)) {
                 const int nb = b / KBLK, kb = b - nb * KBLK;
                 const float *dBase = &sD[(32 * half) * LDD + nb * 32 + l31];
                 const float *xBase = &sZ[(32 * half) * LDZ + kb * 32 + l31];
@@ -276,16 +277,26 @@ int fb_blocks(int n) { return n <= 32 ? 1 : (n <= 64 ? 2 : 4); }
 
 // Resident workgroups per CU of one instantiation (registers and LDS both count), asked of the runtime
 // once; also raises the dynamic-LDS limit of the kernel (> 64 KB has to be requested).
+template <int NBLK, int KBLK, bool POOLED>
+int fb_resident_of();
+
 template <int NBLK, int KBLK>
 int fb_resident()
+{
+    return fb_resident_of<NBLK, KBLK, false>() < fb_resident_of<NBLK, KBLK, true>() ? fb_resident_of<NBLK, KBLK, false>()
+                                                                                   : fb_resident_of<NBLK, KBLK, true>();
+}
+
+template <int NBLK, int KBLK, bool POOLED>
+int fb_resident_of()
 {
     static int cached = -1;
     if (cached >= 0) return cached;
     constexpr int lds = fb_lds_bytes<NBLK, KBLK>();
-    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_fused_kernel<NBLK, KBLK>);
+    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_fused_kernel<NBLK, KBLK, POOLED>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_fused_kernel<NBLK, KBLK>, FB_THREADS, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_fused_kernel<NBLK, KBLK, POOLED>, FB_THREADS, lds) != hipSuccess) return 0;
     cached = n < 1 ? 0 : (n > 4 ? 4 : n);
     return cached;
 }
@@ -303,7 +314,10 @@ int fb_resident_rt(int nblk, int kblk)
 template <int NBLK, int KBLK>
 int fb_launch(const BwdArgs &a, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((mlp_bwd_fused_kernel<NBLK, KBLK>), dim3(grid), dim3(FB_THREADS), (fb_lds_bytes<NBLK, KBLK>()), stream, a);
+    if (a.argk)
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<NBLK, KBLK, true>), dim3(grid), dim3(FB_THREADS), (fb_lds_bytes<NBLK, KBLK>()), stream, a);
+    else
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<NBLK, KBLK, false>), dim3(grid), dim3(FB_THREADS), (fb_lds_bytes<NBLK, KBLK>()), stream, a);
     return PN2_LAUNCH_RC();
 }
 
@@ -359,6 +373,7 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.w = w; a.ldw = ldw; a.x = x; a.ldx = ldx;
     a.ascale = ascale; a.ashift = ashift; a.amean = amean; a.ainvstd = ainvstd; a.gp = gp; a.ldgp = ldgp;
     a.stat_partial = stat_partial; a.dw_partial = dw_partial; a.M = M; a.N = N; a.K = K;
+    a.dbg = pn2::tune_get("fb_dbg", 0);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int nblk = fb_blocks(N), kblk = fb_blocks(K);
     int rc = PN2_ERR_UNSUPPORTED;

@@ -155,33 +155,33 @@ class SemSegTrainer:
         self._static_x = blocks_cf.clone()
         self._static_y = target.clone()
         if self.prefetch:
-            # static pyramid buffers: `cur` is read by the forward, `next` is (re)written by the
-            # side branch of every replay and copied into `cur` at the start of the following one
+            # static pyramid buffer `cur`: read by forward and backward of a replay; the side branch of the
+            # same replay computes the next batch's pyramid and, once backward is done, copies it into
+            # `cur` while the optimizer runs on the main stream (so no copy sits on the critical path)
             self._static_next_x = blocks_cf.clone()
             torch.cuda.current_stream().wait_stream(self._side)
             with torch.no_grad():
                 self._geo_cur = [t.clone() for t in self.model.compute_geometry(self._static_x)]
-            self._geo_next = [t.clone() for t in self._geo_cur]
             torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fwd_bwd, pool=pool):
-            geo = None
+            geo = new_geo = None
             if self.prefetch:
-                for cur, nxt in zip(self._geo_cur, self._geo_next):
-                    cur.copy_(nxt)
                 new_geo = self._launch_prefetch(self._static_next_x)      # fork: side branch of the graph
-                with torch.cuda.stream(self._side):
-                    for nxt, new in zip(self._geo_next, new_geo):
-                        nxt.copy_(new)
                 geo = self._geo_cur
             self._static_loss = self._forward_backward(self._static_x, self._static_y, geo)
             if self.prefetch:
-                torch.cuda.current_stream().wait_stream(self._side)       # join
+                self._side.wait_stream(torch.cuda.current_stream())       # backward no longer reads `cur`
+                with torch.cuda.stream(self._side):
+                    for cur, new in zip(self._geo_cur, new_geo):
+                        cur.copy_(new)
             if exchange:
                 self.grads.pack()                       # .grad become views of one flat buffer
             else:
                 self.optimizer.step()
+            if self.prefetch:
+                torch.cuda.current_stream().wait_stream(self._side)       # join
         if exchange:
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, pool=pool):
