@@ -18,6 +18,9 @@ namespace pn2 {
 int launch_ball_query_mfma(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
                            int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
                            hipStream_t stream);
+int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
+                           int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
+                           hipStream_t stream);
 }
 
 namespace {
@@ -390,6 +393,12 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
     // each takes several centroids.  Few centroids (deep levels): small workgroups, two
     // centroids per wave, for parallelism.
     const long long total = (long long)B * S;
+    // Many centroids over a large block that fits LDS: cell-pruned candidates (pn2_ball_grid.hip).
+    if (total >= 4096 && N >= pn2::tune_get("bq_grid_minn", 2048) && pn2::tune_get("bq_grid", 1)) {
+        const int rc = pn2::launch_ball_query_grid(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped,
+                                                   err_count, stream);
+        if (rc != PN2_ERR_UNSUPPORTED) return rc;
+    }
     // Many centroids over a block that fits LDS: the matrix-core kernel (pn2_ball_mfma.hip).
     if (total >= 4096 && pn2::tune_get("bq_mfma", 1)) {
         const int rc = pn2::launch_ball_query_mfma(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped,

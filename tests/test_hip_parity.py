@@ -360,3 +360,47 @@ def test_full_size_properties_b16(pn2, orc, synth):
         want_idx = orc.query_ball_point(0.1, 32, xyz[b:b + 1], cxyz)
         assert np.array_equal(idx[b:b + 1], want_idx)
         assert np.array_equal(grouped[b:b + 1], orc.group_points(xyz[b:b + 1], cxyz, blocks[b:b + 1], want_idx))
+
+
+@pytest.mark.parametrize("case", ["offset", "huge_coords", "nan_block", "outside", "clustered", "degenerate_axis"])
+def test_ball_query_cell_pruned_path(pn2, orc, case):
+    """B*S >= 4096 and N >= 2048 take the cell-pruned kernel (pn2_ball_grid.hip).  Its candidate set must
+    never change the result: coordinates far from the origin (rounding of the reference's distance
+    expression grows with |p|^2), non-finite coordinates, centroids outside the cloud's bounding box,
+    dense clusters (hit-list overflow -> ordered rescan) and clouds flat in one axis."""
+    rs = np.random.RandomState(len(case))
+    B, N, S, K, D, radius = 8, 4096, 512, 32, 9, 0.1
+    xyz = rs.uniform(0.0, 1.0, size=(B, N, 3)).astype(np.float32)
+    if case == "offset":
+        xyz += np.array([30.0, -12.0, 4.0], np.float32)
+    elif case == "huge_coords":
+        xyz = (xyz * 3.0 + np.array([690000.0, 5330000.0, 500.0])).astype(np.float32)   # raw CRS metres: fp32 noise >> r^2
+        radius = 1.0
+    elif case == "clustered":
+        xyz[:, : N // 2] = 0.5 + (xyz[:, : N // 2] - 0.5) * 0.05                   # 2048 points inside a 5 cm cube
+    elif case == "degenerate_axis":
+        xyz[:, :, 2] = 0.25
+    pick = np.stack([rs.choice(N, S, replace=False) for _ in range(B)])
+    new_xyz = orc.index_points(xyz, pick)
+    if case == "outside":
+        new_xyz[:, ::3] += np.array([0.0, 1.5, 0.0], np.float32)                    # empty balls far outside the box
+        new_xyz[:, 1::3] -= np.array([0.05, 0.0, 0.0], np.float32)
+    if case == "nan_block":
+        xyz[1, 100, 0] = np.nan
+        xyz[2, 7] = np.inf
+        new_xyz[3, 5, 2] = np.nan
+    pts = rs.normal(size=(B, N, D)).astype(np.float32)
+    want = orc.query_ball_point(radius, K, xyz, new_xyz, allow_empty=(case == "outside"))
+    idx = host(pn2.U.query_ball_point(radius, K, dev(pn2, xyz), dev(pn2, new_xyz)))
+    assert np.array_equal(idx, want)
+    if case == "outside":
+        with pytest.raises(IndexError):
+            pn2.ops.check_errors()
+        return
+    idx2, grouped = pn2.ops.ball_query_group(radius, K, dev(pn2, xyz), dev(pn2, new_xyz), dev(pn2, pts))
+    assert np.array_equal(host(idx2), want)
+    ok = want < N
+    if ok.all():
+        ref = orc.group_points(xyz, new_xyz, pts, want)
+        assert np.array_equal(host(grouped), ref, equal_nan=True)
+    pn2.ops._ERR.clear()
