@@ -175,7 +175,7 @@ def main():
                                    "npoint=[1024,256,64,16] nsample=32, 18 classes (BASELINE configs[1])" % args.kind,
                        "global_batch": world * PER_GPU_BATCH, "points_per_block": BLOCK_POINTS,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "ball_query_group_mfma_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16)",
+            "roofline": {"bound": "hbm", "kernel": "ball_query_group_grid_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": k_ms},
         }
