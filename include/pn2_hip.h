@@ -188,6 +188,21 @@ int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long lon
 int pn2_bn_bwd_finalize(const float *partial, int P, int C, double count, float *dgamma, float *dbeta,
                         float *c1, float *c2, pn2_stream_t stream);
 
+/* ---- transposed index tables: atomic-free, order-fixed backward of the gather operators ---------------
+ * The autograd of index_points / grouping (models/pointnet2_utils.py:43-60, :127-132) and of the 3-NN
+ * interpolation (:296-303) is a scatter-add through idx.  pn2_invert_index turns idx [B][E] (values in
+ * [0, Nkeys); others are dropped) into per-key lists: offsets [B][Nkeys+1], entries [B][E] (entry numbers,
+ * ascending inside a list, -1 behind the last list).  E <= 24576, Nkeys <= 8192 per batch, else
+ * PN2_ERR_UNSUPPORTED (callers keep the scatter-add operators).
+ * pn2_gather_sum: out[b][key][c] = sum_{e in list(b,key)} w[b][e] * src[b][e / ediv][col0 + c], c < D
+ * (weight nullable = 1; src rows [B][rows_src][lds]).  Grouping: src = d grouped [B][S*K][ldg], col0 = 3,
+ * ediv = 1.  Interpolation: src = d out [B][N][D], weight = weight3 [B][N*3], ediv = 3. */
+int pn2_invert_index(const int64_t *idx, int B, long long E, int Nkeys, int32_t *offsets, int32_t *entries,
+                     pn2_stream_t stream);
+int pn2_gather_sum(const float *src, long long rows_src, int lds, int col0, const int32_t *offsets,
+                   const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
+                   float *out, pn2_stream_t stream);
+
 /* ---- segmentation head tail and loss (caller of the hot path) ------------------------
  * x = conv2(x); x = F.log_softmax(x, dim=1)                   models/pointnet2_sem_seg.py:37-38
  * logp[M][C] = log_softmax(y[M][K] * w[C][K]^T + bias[C]) per row.  K <= 128, K % 4 == 0, C <= 32. */

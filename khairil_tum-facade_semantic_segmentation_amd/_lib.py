@@ -38,6 +38,8 @@ SIGNATURES = {
     "pn2_bn_bwd_reduce_partials": [_cl],
     "pn2_bn_bwd_reduce": [_vp, _ci, _vp, _ci, _cl, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_bn_bwd_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _vp, _vp, _vp],
+    "pn2_invert_index": [_vp, _ci, _cl, _ci, _vp, _vp, _vp],
+    "pn2_gather_sum": [_vp, _cl, _ci, _ci, _vp, _vp, _vp, _cl, _ci, _ci, _ci, _ci, _vp, _vp],
     "pn2_head_logits": [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],
     "pn2_head_logits_partials": [_ci],
     "pn2_head_logits_backward": [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],

@@ -1,0 +1,216 @@
+// Transposed form of the two gather operators' backward passes.
+//
+// index_points / grouping (reference models/pointnet2_utils.py:43-60, :127-132) and the 3-NN
+// interpolation (:296-303) read rows through an index; their autograd is a scatter-add of the incoming
+// gradient rows into the indexed rows.  A scatter-add needs float atomics (arbitrary summation order,
+// a zero-filled target).  The index tables depend on the coordinates only, so they can be transposed
+// once per batch, off the critical path, into "which entries point at row j" lists
+// (pn2_invert_index); the backward is then a plain gather-sum per row (pn2_gather_sum): no atomics,
+// no zero fill, and a fixed summation order (entries ascending) -> run-to-run identical gradients.
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int INV_THREADS = 1024;
+constexpr int INV_MAX_KEYS = 8192;            // keys per batch handled in LDS
+constexpr int INV_MAX_ENTRIES = 24576;        // entries per batch handled in LDS (96 KB of int32)
+
+// 16-byte loads from rows that are only 4-byte aligned (gradient columns behind the 3 xyz columns)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// One workgroup per batch: histogram of the keys, exclusive scan, scatter of the entry ids, then every
+// key's list is put in ascending order (lists are short: 3N/S resp. SK/N entries on average).
+__global__ __launch_bounds__(INV_THREADS) void invert_index_kernel(const int64_t *__restrict__ idx, long long E, int Nkeys,
+                                                                  int32_t *__restrict__ offsets, int32_t *__restrict__ entries)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *cnt = reinterpret_cast<int *>(smem);                      // [Nkeys + 1] counts -> starts
+    int *fill = cnt + (Nkeys + 1);                                 // [Nkeys] next free slot
+    int *list = fill + Nkeys;                                      // [E]
+    __shared__ int wsum[INV_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t *bi = idx + (size_t)b * E;
+    for (int i = tid; i <= Nkeys; i += INV_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += INV_THREADS) {
+        const int64_t k = bi[e];
+        if (k >= 0 && k < Nkeys) atomicAdd(&cnt[(int)k], 1);
+    }
+    __syncthreads();
+    // exclusive scan over Nkeys counts: chunk per thread, wave scan, wave offsets
+    const int per = (Nkeys + INV_THREADS - 1) / INV_THREADS;
+    const int k0 = tid * per;
+    int s = 0;
+    for (int i = 0; i < per; ++i)
+        if (k0 + i < Nkeys) s += cnt[k0 + i];
+    int inc = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    int run = off + inc - s;
+    for (int i = 0; i < per; ++i)
+        if (k0 + i < Nkeys) {
+            const int c = cnt[k0 + i];
+            cnt[k0 + i] = run;
+            fill[k0 + i] = run;
+            run += c;
+        }
+    if (tid == INV_THREADS - 1) cnt[Nkeys] = run;                  // total number of valid entries
+    __syncthreads();
+    // entries are appended batch by batch in ascending order (a barrier between batches), so a list is
+    // ascending except among entries of one batch; the insertion sort below only repairs those
+    for (long long e0 = 0; e0 < E; e0 += INV_THREADS) {
+        const long long e = e0 + tid;
+        if (e < E) {
+            const int64_t k = bi[e];
+            if (k >= 0 && k < Nkeys) list[atomicAdd(&fill[(int)k], 1)] = (int)e;
+        }
+        __syncthreads();
+    }
+    // ascending order inside every list (insertion sort, one thread per key)
+    for (int k = tid; k < Nkeys; k += INV_THREADS) {
+        const int a = cnt[k], z = cnt[k + 1];
+        for (int i = a + 1; i < z; ++i) {
+            const int v = list[i];
+            int j = i - 1;
+            while (j >= a && list[j] > v) { list[j + 1] = list[j]; --j; }
+            list[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    int32_t *bo = offsets + (size_t)b * (Nkeys + 1);
+    int32_t *be = entries + (size_t)b * E;
+    for (int i = tid; i <= Nkeys; i += INV_THREADS) bo[i] = cnt[i];
+    const int total = cnt[Nkeys];
+    for (int e = tid; e < E; e += INV_THREADS) be[e] = e < total ? list[e] : -1;
+}
+
+// out[b][key][c] = sum over the key's entries e (ascending) of w[b][e] * src[b][e / ediv][col0 + c].
+// LPR lanes per (b, key) row (a lane owns 4 consecutive columns per pass of 4*LPR columns), 64/LPR rows
+// per wave, 4 entries in flight.
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ src, long long rows_src, int lds, int col0,
+                                                         const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
+                                                         const float *__restrict__ weight, long long E, int ediv, int B, int Nkeys,
+                                                         int D, float *__restrict__ out)
+{
+    constexpr int RPB = 256 / LPR;                                 // rows per workgroup
+    const int sub = threadIdx.x % LPR;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
+    if (row >= (long long)B * Nkeys) return;
+    const int b = (int)(row / Nkeys), key = (int)(row - (long long)b * Nkeys);
+    const int32_t *bo = offsets + (size_t)b * (Nkeys + 1);
+    const int a = bo[key], z = bo[key + 1];
+    const int32_t *be = entries + (size_t)b * E;
+    const float *bw = weight ? weight + (size_t)b * E : nullptr;
+    const float *bs = src + (size_t)b * rows_src * lds + col0;
+    float *orow = out + (size_t)row * D;
+    for (int c = sub * 4; c < D; c += 4 * LPR) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int i = a;
+        for (; i + 4 <= z; i += 4) {
+            int e[4];
+            float w[4];
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e[u] = be[i + u];
+                w[u] = bw ? bw[e[u]] : 1.0f;
+                const f32x4u t = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e[u] / ediv) * lds + c);
+                v[u] = make_float4(t.x, t.y, t.z, t.w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w;
+            }
+        }
+        for (; i < z; ++i) {
+            const int e = be[i];
+            const float w = bw ? bw[e] : 1.0f;
+            const f32x4u v = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e / ediv) * lds + c);
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        *reinterpret_cast<float4 *>(orow + c) = acc;
+    }
+}
+
+// any width / alignment: one wave per row, one column per lane and pass
+__global__ __launch_bounds__(256) void gather_sum_scalar_kernel(const float *__restrict__ src, long long rows_src, int lds, int col0,
+                                                                const int32_t *__restrict__ offsets,
+                                                                const int32_t *__restrict__ entries, const float *__restrict__ weight,
+                                                                long long E, int ediv, int B, int Nkeys, int D, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * Nkeys) return;
+    const int b = (int)(row / Nkeys), key = (int)(row - (long long)b * Nkeys);
+    const int32_t *bo = offsets + (size_t)b * (Nkeys + 1);
+    const int a = bo[key], z = bo[key + 1];
+    const int32_t *be = entries + (size_t)b * E;
+    const float *bw = weight ? weight + (size_t)b * E : nullptr;
+    const float *bs = src + (size_t)b * rows_src * lds + col0;
+    float *orow = out + (size_t)row * D;
+    for (int c = lane; c < D; c += 64) {
+        float acc = 0.f;
+        for (int i = a; i < z; ++i) {
+            const int e = be[i];
+            acc += (bw ? bw[e] : 1.0f) * bs[(size_t)(e / ediv) * lds + c];
+        }
+        orow[c] = acc;
+    }
+}
+
+}  // namespace
+
+PN2_EXPORT int pn2_invert_index(const int64_t *idx, int B, long long E, int Nkeys, int32_t *offsets, int32_t *entries,
+                                pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(idx); PN2_REQUIRE_PTR(offsets); PN2_REQUIRE_PTR(entries);
+    if (B < 0 || E <= 0 || Nkeys <= 0) return PN2_ERR_SHAPE;
+    if (E > INV_MAX_ENTRIES || Nkeys > INV_MAX_KEYS) return PN2_ERR_UNSUPPORTED;
+    if (B == 0) return PN2_OK;
+    const size_t lds = ((size_t)(2 * Nkeys + 1) + (size_t)E) * sizeof(int);
+    if (lds > 150 * 1024) return PN2_ERR_UNSUPPORTED;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(invert_index_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(invert_index_kernel, dim3((unsigned)B), dim3(INV_THREADS), lds, static_cast<hipStream_t>(stream_), idx, E,
+                       Nkeys, offsets, entries);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_gather_sum(const float *src, long long rows_src, int lds, int col0, const int32_t *offsets,
+                              const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
+                              float *out, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(src); PN2_REQUIRE_PTR(offsets); PN2_REQUIRE_PTR(entries); PN2_REQUIRE_PTR(out);
+    if (B < 0 || E <= 0 || Nkeys <= 0 || D <= 0 || ediv <= 0 || rows_src <= 0 || col0 < 0 || lds < col0 + D) return PN2_ERR_SHAPE;
+    if (B == 0) return PN2_OK;
+    const long long rows = (long long)B * Nkeys;
+    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int lpr = !vec4 ? 0 : (D <= 32 ? 8 : (D <= 64 ? 16 : (D <= 128 ? 32 : 64)));
+    const long long rpb = lpr ? 256 / lpr : 4;
+    const long long blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
+#define PN2_GS(L) hipLaunchKernelGGL(gather_sum_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, \
+                                     offsets, entries, weight, E, ediv, B, Nkeys, D, out)
+    if (lpr == 8) PN2_GS(8);
+    else if (lpr == 16) PN2_GS(16);
+    else if (lpr == 32) PN2_GS(32);
+    else if (lpr == 64) PN2_GS(64);
+    else
+        hipLaunchKernelGGL(gather_sum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, offsets,
+                           entries, weight, E, ediv, B, Nkeys, D, out);
+#undef PN2_GS
+    return PN2_LAUNCH_RC();
+}

@@ -18,6 +18,9 @@ PRO_NONE, PRO_BN_RELU, PRO_BN_BWD = 0, 1, 2
 # fill idle CUs.  Measured on MI355X: 5.06 ms/step with it against 4.81 without (the two kernel
 # families thrash each other), so it is OFF by default; PN2_DW_SIDE_STREAM=1 enables it.
 _DW_SIDE = os.environ.get("PN2_DW_SIDE_STREAM", "0") == "1"
+# ... but for stacks with few rows (deep levels: neither the dX GEMM nor the dW kernel fills the 256 CUs) the
+# parallel branch does pay; PN2_DW_SIDE_MAX_ROWS is the largest M that uses it (0 = never).
+_DW_SIDE_MAX_ROWS = int(os.environ.get("PN2_DW_SIDE_MAX_ROWS", "0"))
 # Layers with at most 128 input and output channels run their whole backward (dX, dW, db, statistics for
 # the layer below) in one pass over the activations (pn2_mlp_bwd_layer); PN2_FUSED_BWD=0 keeps the
 # two-kernel path (pn2_mlp_gemm prologue 2 + pn2_mlp_dw) for A/B runs.
@@ -135,7 +138,7 @@ class _MLPStack(torch.autograd.Function):
         gy = gy.to(torch.float32).contiguous()
         grads = [None] * (4 * L)
         main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if _DW_SIDE else None
+        side = _side_stream(dev) if (_DW_SIDE or M <= _DW_SIDE_MAX_ROWS) else None
         with torch.cuda.device(dev):
             # BatchNorm+ReLU backward statistics of the top layer
             zt = zs[-1]
@@ -167,7 +170,7 @@ class _MLPStack(torch.autograd.Function):
                 grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
                 consts = (sc, sh, mu, istd, c1, c2)
                 Pf = 0
-                if _FUSED_BWD and side is None and (l > 0 or x2 is None):
+                if _FUSED_BWD and (l > 0 or x2 is None):
                     Pf = lib.pn2_mlp_bwd_layer_partials(M, Co, Ci)
                 if Pf:
                     pk = pool_k if g_argk is not None else 0

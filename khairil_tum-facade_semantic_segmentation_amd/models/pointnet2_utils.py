@@ -151,12 +151,13 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
 
     def forward_cl(self, xyz, points, start=None, geometry=None):
         """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C'].
-        `geometry` = a precomputed (new_xyz, idx) pair from geometry()."""
+        `geometry` = a precomputed (new_xyz, idx[, inverse index]) tuple from geometry()."""
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz, points)
         elif geometry is not None:
-            new_xyz, idx = geometry
-            grouped = ops.group_points(xyz, new_xyz, points, idx, pad_to=4)
+            new_xyz, idx = geometry[0], geometry[1]
+            inv = geometry[2] if len(geometry) > 2 else None       # ops.invert_index(idx, N): atomic-free backward
+            grouped = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start,
                                                 pad_to=4)
@@ -212,14 +213,15 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
 
     def forward_cl(self, xyz1, xyz2, points1, points2, nn=None):
         """Channel-last: xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,D1]|None, points2 [B,S,D2] -> [B,N,C'].
-        `nn` = a precomputed (idx3, weight3) pair from ops.three_nn(xyz1, xyz2)."""
+        `nn` = a precomputed (idx3, weight3[, inverse index]) tuple from ops.three_nn(xyz1, xyz2)."""
         B, N, _ = xyz1.shape
         S = xyz2.shape[1]
         if S == 1:                                      # :293-294
             interpolated = points2.expand(B, N, points2.shape[-1])
         else:
-            idx3, w3 = nn if nn is not None else ops.three_nn(xyz1, xyz2)   # :296-302
-            interpolated = ops.three_interpolate(points2, idx3, w3)   # :303
+            idx3, w3 = (nn[0], nn[1]) if nn is not None else ops.three_nn(xyz1, xyz2)   # :296-302
+            inv = nn[2] if nn is not None and len(nn) > 2 else None    # ops.invert_index(idx3, S)
+            interpolated = ops.three_interpolate(points2, idx3, w3, inv=inv)   # :303
         D2 = interpolated.shape[-1]
         if points1 is None:                             # :305-309 (the concat is never materialised)
             y = _mlp(interpolated.reshape(B * N, D2), None, self.mlp_convs, self.mlp_bns)

@@ -179,14 +179,49 @@ def ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to=1):
     return _BallQueryGroup.apply(xyz, new_xyz, points, radius, nsample, pad_to)
 
 
-def index_points_backward(grad_out, idx, N, D, col0=0):
-    """grad_points[B,N,D] = scatter-add of grad_out[B,...,Cg][..., col0:col0+D] at idx."""
+def invert_index(idx, nkeys):
+    """Transposed index table of idx [B, ...] with values in [0, nkeys): (offsets [B,nkeys+1] int32,
+    entries [B,E] int32) for the gather-sum form of the backward passes, or None when the table is too
+    large for the on-chip transposition (the scatter-add operators are used then)."""
+    dev = _dev(idx)
+    lib = _lib.load()
+    idx = _i64c(idx)
+    B = idx.shape[0]
+    E = idx.numel() // max(B, 1)
+    off = torch.empty((B, nkeys + 1), dtype=torch.int32, device=dev)
+    ent = torch.empty((B, E), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_invert_index(_ptr(idx), B, E, nkeys, _ptr(off), _ptr(ent), _stream(dev))
+    if rc == -3:                                          # PN2_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc, "pn2_invert_index")
+    return off, ent
+
+
+def _gather_sum(src, rows_src, col0, inv, weight, ediv, nkeys, D):
+    dev = _dev(src)
+    lib = _lib.load()
+    off, ent = inv
+    B, E = ent.shape
+    out = torch.empty((B, nkeys, D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_gather_sum(_ptr(src), rows_src, src.shape[-1], col0, _ptr(off), _ptr(ent), _ptr(weight), E, ediv, B,
+                                nkeys, D, _ptr(out), _stream(dev))
+    _lib.check(rc, "pn2_gather_sum")
+    return out
+
+
+def index_points_backward(grad_out, idx, N, D, col0=0, inv=None):
+    """grad_points[B,N,D] = scatter-add of grad_out[B,...,Cg][..., col0:col0+D] at idx; with
+    inv = invert_index(idx, N) the same sum as an atomic-free gather in a fixed order."""
     dev = _dev(grad_out, idx)
     lib = _lib.load()
     grad_out, idx = _f32c(grad_out), _i64c(idx)
     B = idx.shape[0]
     M = idx.numel() // max(B, 1)
     Cg = grad_out.shape[-1]
+    if inv is not None:
+        return _gather_sum(grad_out, M, col0, inv, None, 1, N, D)
     gp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.pn2_index_points_backward(_ptr(grad_out), _ptr(idx), B, N, D, M, Cg, col0, _ptr(gp), _stream(dev))
@@ -227,7 +262,7 @@ def index_points(points, idx):
 
 class _GroupPoints(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, idx, pad_to):
+    def forward(ctx, xyz, new_xyz, points, idx, pad_to, inv_off=None, inv_ent=None):
         dev = _dev(xyz, new_xyz, points, idx)
         lib = _lib.load()
         B, N, _ = xyz.shape
@@ -239,25 +274,29 @@ class _GroupPoints(torch.autograd.Function):
             rc = lib.pn2_group_points(_ptr(xyz), _ptr(new_xyz), _ptr(points), _ptr(idx), B, N, S, K, D, _ptr(out), ldg,
                                       _ptr(_err_word(dev)), _stream(dev))
         _lib.check(rc, "pn2_group_points")
-        ctx.save_for_backward(idx)
+        ctx.has_inv = inv_off is not None
+        ctx.save_for_backward(idx, *((inv_off, inv_ent) if ctx.has_inv else ()))
         ctx.shape = (N, D)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
+        inv = ctx.saved_tensors[1:3] if ctx.has_inv else None
         N, D = ctx.shape
         if D == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None, None
-        return None, None, index_points_backward(gout, idx, N, D, col0=3), None, None
+            return None, None, None, None, None, None, None
+        return None, None, index_points_backward(gout, idx, N, D, col0=3, inv=inv), None, None, None, None
 
 
-def group_points(xyz, new_xyz, points, idx, pad_to=1):
-    """[xyz[idx]-new_xyz, points[idx]] for a given idx (models/pointnet2_utils.py:127-132)."""
+def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None):
+    """[xyz[idx]-new_xyz, points[idx]] for a given idx (models/pointnet2_utils.py:127-132).
+    inv = invert_index(idx, N): the backward then gathers instead of scatter-adding."""
     dev = _dev(xyz, new_xyz, points, idx)
     if points is not None:
         points = points.to(torch.float32).contiguous()
-    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to)
+    io, ie = inv if inv is not None else (None, None)
+    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to, io, ie)
     _after_fault_op(dev, "group_points")
     return out
 
@@ -281,7 +320,7 @@ def three_nn(xyz1, xyz2, want_dist=False):
 
 class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points2, idx3, weight3):
+    def forward(ctx, points2, idx3, weight3, inv_off=None, inv_ent=None):
         dev = _dev(points2, idx3, weight3)
         lib = _lib.load()
         B, S, D = points2.shape
@@ -291,25 +330,30 @@ class _ThreeInterpolate(torch.autograd.Function):
             rc = lib.pn2_three_interpolate(_ptr(points2), _ptr(idx3), _ptr(weight3), B, N, S, D, _ptr(out),
                                            _stream(dev))
         _lib.check(rc, "pn2_three_interpolate")
-        ctx.save_for_backward(idx3, weight3)
+        ctx.has_inv = inv_off is not None
+        ctx.save_for_backward(idx3, weight3, *((inv_off, inv_ent) if ctx.has_inv else ()))
         ctx.shape = (B, N, S, D)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        idx3, weight3 = ctx.saved_tensors
+        idx3, weight3 = ctx.saved_tensors[:2]
         B, N, S, D = ctx.shape
         dev = gout.device
         lib = _lib.load()
         gout = _f32c(gout)
+        if ctx.has_inv:
+            return _gather_sum(gout, N, 0, ctx.saved_tensors[2:4], weight3, 3, S, D), None, None, None, None
         g2 = torch.zeros((B, S, D), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.pn2_three_interpolate_backward(_ptr(gout), _ptr(idx3), _ptr(weight3), B, N, S, D, _ptr(g2),
                                                     _stream(dev))
         _lib.check(rc, "pn2_three_interpolate_backward")
-        return g2, None, None
+        return g2, None, None, None, None
 
 
-def three_interpolate(points2, idx3, weight3):
-    """sum_k points2[idx3[...,k]] * weight3[...,k]  (models/pointnet2_utils.py:303)."""
-    return _ThreeInterpolate.apply(points2.to(torch.float32).contiguous(), _i64c(idx3), _f32c(weight3))
+def three_interpolate(points2, idx3, weight3, inv=None):
+    """sum_k points2[idx3[...,k]] * weight3[...,k]  (models/pointnet2_utils.py:303).
+    inv = invert_index(idx3, S): the backward then gathers instead of scatter-adding."""
+    io, ie = inv if inv is not None else (None, None)
+    return _ThreeInterpolate.apply(points2.to(torch.float32).contiguous(), _i64c(idx3), _f32c(weight3), io, ie)

@@ -144,7 +144,8 @@ class SemSegTrainer:
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._geo_next = self._launch_prefetch(nxt)  # overlaps with everything below
             for t in self._geo_next:
-                t.record_stream(self._side)
+                if t is not None:
+                    t.record_stream(self._side)
         loss = self._forward_backward(blocks_cf, target, geo)
         self.grads.all_reduce_mean(self.group)
         self.optimizer.step()
@@ -161,7 +162,7 @@ class SemSegTrainer:
             self._static_next_x = blocks_cf.clone()
             torch.cuda.current_stream().wait_stream(self._side)
             with torch.no_grad():
-                self._geo_cur = [t.clone() for t in self.model.compute_geometry(self._static_x)]
+                self._geo_cur = [None if t is None else t.clone() for t in self.model.compute_geometry(self._static_x)]
             torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
@@ -175,7 +176,8 @@ class SemSegTrainer:
                 self._side.wait_stream(torch.cuda.current_stream())       # backward no longer reads `cur`
                 with torch.cuda.stream(self._side):
                     for cur, new in zip(self._geo_cur, new_geo):
-                        cur.copy_(new)
+                        if cur is not None:
+                            cur.copy_(new)
             if exchange:
                 self.grads.pack()                       # .grad become views of one flat buffer
             else:

@@ -241,6 +241,55 @@ def test_gather_and_interpolate_backward(pn2, orc):
     np.testing.assert_allclose(host(tp3.grad), want3, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,N,S,K,D", [(3, 1024, 256, 32, 64), (2, 300, 77, 16, 5), (16, 4096, 1024, 8, 12)])
+def test_transposed_index_backward_matches_scatter_add(pn2, orc, B, N, S, K, D):
+    """pn2_invert_index + pn2_gather_sum (atomic-free, order-fixed) against the oracle's scatter-add for the
+    grouping and the interpolation backward; entry lists ascending; two runs bit-identical."""
+    torch = pn2.torch
+    rs = np.random.RandomState(N + S)
+    xyz = rs.uniform(0, 1, size=(B, N, 3)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    pts = rs.normal(size=(B, N, D)).astype(np.float32)
+    idx = rs.randint(0, N, size=(B, S, K))
+    idx[:, :, 0] = np.arange(S)[None]                      # a point can appear many times, some never
+    tidx = dev(pn2, idx)
+    inv = pn2.ops.invert_index(tidx, N)
+    assert inv is not None
+    off, ent = host(inv[0]), host(inv[1])
+    for b in range(B):
+        assert off[b, 0] == 0 and off[b, -1] == S * K
+        for j in (0, N // 2, N - 1):
+            lst = ent[b, off[b, j]:off[b, j + 1]]
+            assert (np.diff(lst) > 0).all() and (idx[b].reshape(-1)[lst] == j).all()
+    grads = []
+    for _ in range(2):
+        tp = dev(pn2, pts).requires_grad_(True)
+        g = pn2.ops.group_points(dev(pn2, xyz), dev(pn2, new_xyz), tp, tidx, pad_to=4, inv=inv)
+        go = torch.from_numpy(np.random.RandomState(5).normal(size=tuple(g.shape)).astype(np.float32)).cuda()
+        g.backward(go)
+        grads.append(host(tp.grad))
+    assert np.array_equal(grads[0], grads[1])
+    want = orc.index_points_backward(host(go)[..., 3:3 + D], idx, N, D)
+    np.testing.assert_allclose(grads[0], want, rtol=1e-5, atol=1e-5)
+
+    p2 = rs.normal(size=(B, S, D)).astype(np.float32)
+    idx3, w3 = pn2.ops.three_nn(dev(pn2, xyz), dev(pn2, new_xyz))
+    inv3 = pn2.ops.invert_index(idx3, S)
+    assert inv3 is not None
+    tp3 = dev(pn2, p2).requires_grad_(True)
+    o = pn2.ops.three_interpolate(tp3, idx3, w3, inv=inv3)
+    go3 = rs.normal(size=tuple(o.shape)).astype(np.float32)
+    o.backward(dev(pn2, go3))
+    want3 = orc.three_interpolate_backward(go3, host(idx3), host(w3), S)
+    np.testing.assert_allclose(host(tp3.grad), want3, rtol=1e-4, atol=1e-4)
+    pn2.ops._ERR.clear()
+
+
+def test_transposed_index_too_large_is_declined(pn2):
+    idx = pn2.torch.zeros((1, 40000), dtype=pn2.torch.int64).cuda()
+    assert pn2.ops.invert_index(idx, 100) is None
+
+
 # ------------------------------------------------------------------------- whole network
 def _load(pn2, synth, orc, model, K, C):
     filled = synth.fill_state_dict(orc.state_shapes(K, C - 6))
