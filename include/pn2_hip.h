@@ -168,14 +168,17 @@ int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned 
  * the ReLU of the layer below when ascale/ashift/amean/ainvstd are given (x is then that layer's raw z and
  * stat_partial [P][2][K] receives the column sums of gp and gp*xhat; otherwise x is an activation);
  * dw[N][K] = dz^T * act(x), db[N] (nullable).  dw_partial: workspace [P][N][K+1] floats with
- * P = pn2_mlp_bwd_layer_partials(M, N, K) (0: shape not covered -> use pn2_mlp_gemm + pn2_mlp_dw). */
+ * P = pn2_mlp_bwd_layer_partials(M, N, K) (0: shape not covered -> use pn2_mlp_gemm + pn2_mlp_dw).
+ * With c1_below/c2_below (and optionally dgamma_below/dbeta_below, all [K]) the pn2_bn_bwd_finalize of
+ * stat_partial (count = M) runs in the same launch as the slab reduction. */
 int pn2_mlp_bwd_layer_partials(int M, int N, int K);
 int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
                       const float *scale, const float *shift, const float *mean, const float *invstd,
                       const float *c1, const float *c2, const float *w, int ldw, const float *x, int ldx,
                       const float *ascale, const float *ashift, const float *amean, const float *ainvstd,
                       float *gp, int ldgp, float *stat_partial, float *dw_partial, float *dw, float *db,
-                      int M, int N, int K, pn2_stream_t stream);
+                      float *dgamma_below, float *dbeta_below, float *c1_below, float *c2_below, int M, int N, int K,
+                      pn2_stream_t stream);
 
 /* BatchNorm+ReLU backward statistics of the top layer of a stack: partial
  * [pn2_bn_bwd_reduce_partials(rows)][2][C] sums of gh and gh*xh over rows (rows = M, or the

@@ -1172,13 +1172,12 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
 
 // dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order:
 // 32 elements x 8 partial slices per workgroup, slices combined in order through LDS.
-__global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
-                                                        float *__restrict__ dw, float *__restrict__ db)
+__device__ __forceinline__ void dw_reduce_block(int block, const float *__restrict__ partial, int P, int N, int K,
+                                                float *__restrict__ dw, float *__restrict__ db, float (*sS)[33])
 {
-    __shared__ float sS[32][33];
     const int Kout = K + 1;
     const int el = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;
+    const int e = block * 32 + el;
     const size_t stride = (size_t)N * Kout;
     float s = 0.f;
     if (e < N * Kout) {
@@ -1198,6 +1197,13 @@ __global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict
     const int n = e / Kout, k = e - n * Kout;
     if (k < K) dw[(size_t)n * K + k] = s;
     else if (db) db[n] = s;
+}
+
+__global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
+                                                        float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float sS[32][33];
+    dw_reduce_block(blockIdx.x, partial, P, N, K, dw, db, sS);
 }
 
 // Column partial sums of gh and gh*xh over rows for the TOP layer of a stack (the inner layers
@@ -1239,14 +1245,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
 }
 
 // partial[P][2][C] -> dbeta = sum gh, dgamma = sum gh*xh, c1 = dbeta/count, c2 = dgamma/count
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int P, int C,
-                                                              double count, float *__restrict__ dgamma,
-                                                              float *__restrict__ dbeta, float *__restrict__ c1,
-                                                              float *__restrict__ c2)
+__device__ __forceinline__ void bn_bwd_finalize_block(int block, const float *__restrict__ partial, int P, int C, double count,
+                                                      float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                      float *__restrict__ c1, float *__restrict__ c2, double (*sS)[33],
+                                                      double (*sQ)[33])
 {
-    __shared__ double sS[32][33], sQ[32][33];
     const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int c = block * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
@@ -1273,6 +1278,31 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     if (dgamma) dgamma[c] = (float)q;
     c1[c] = (float)(s / count);
     c2[c] = (float)(q / count);
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int P, int C,
+                                                              double count, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, float *__restrict__ c1,
+                                                              float *__restrict__ c2)
+{
+    __shared__ double sS[32][33], sQ[32][33];
+    bn_bwd_finalize_block(blockIdx.x, partial, P, C, count, dgamma, dbeta, c1, c2, sS, sQ);
+}
+
+// Both reductions that follow a layer's backward kernel in ONE launch (every launch costs a few
+// microseconds of fixed time): blocks [0, nred) sum the dW slabs, the rest finalize the BatchNorm
+// statistics of the layer below.
+__global__ __launch_bounds__(1024) void bwd_post_kernel(const float *__restrict__ dw_partial, int P, int N, int K,
+                                                       float *__restrict__ dw, float *__restrict__ db, int nred,
+                                                       const float *__restrict__ stat_partial, int C, double count,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                       float *__restrict__ c1, float *__restrict__ c2)
+{
+    __shared__ double sS[32][33], sQ[32][33];
+    if ((int)blockIdx.x < nred)
+        dw_reduce_block(blockIdx.x, dw_partial, P, N, K, dw, db, reinterpret_cast<float (*)[33]>(sQ));
+    else
+        bn_bwd_finalize_block(blockIdx.x - nred, stat_partial, P, C, count, dgamma, dbeta, c1, c2, sS, sQ);
 }
 
 inline unsigned grid_for(long long total, int threads)
@@ -1461,6 +1491,15 @@ int pn2::launch_dw_reduce(const float *partial, int P, int N, int K, float *dw, 
 {
     const int total = N * (K + 1);
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(1024), 0, stream, partial, P, N, K, dw, db);
+    return PN2_LAUNCH_RC();
+}
+
+int pn2::launch_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial, int C,
+                         double count, float *dgamma, float *dbeta, float *c1, float *c2, hipStream_t stream)
+{
+    const int nred = (N * (K + 1) + 31) / 32, nfin = (C + 31) / 32;
+    hipLaunchKernelGGL(bwd_post_kernel, dim3(nred + nfin), dim3(1024), 0, stream, dw_partial, P, N, K, dw, db, nred, stat_partial, C,
+                       count, dgamma, dbeta, c1, c2);
     return PN2_LAUNCH_RC();
 }
 

@@ -352,7 +352,8 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
                                  const float *c1, const float *c2, const float *w, int ldw, const float *x, int ldx,
                                  const float *ascale, const float *ashift, const float *amean, const float *ainvstd,
                                  float *gp, int ldgp, float *stat_partial, float *dw_partial, float *dw, float *db,
-                                 int M, int N, int K, pn2_stream_t stream_)
+                                 float *dgamma_below, float *dbeta_below, float *c1_below, float *c2_below, int M, int N,
+                                 int K, pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(g); PN2_REQUIRE_PTR(z); PN2_REQUIRE_PTR(scale); PN2_REQUIRE_PTR(shift); PN2_REQUIRE_PTR(mean);
     PN2_REQUIRE_PTR(invstd); PN2_REQUIRE_PTR(c1); PN2_REQUIRE_PTR(c2); PN2_REQUIRE_PTR(w); PN2_REQUIRE_PTR(x);
@@ -361,6 +362,7 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     const bool masked = ascale != nullptr;
     if (masked && (!ashift || !amean || !ainvstd)) return PN2_ERR_NULL;
     if (stat_partial && (!masked || !gp)) return PN2_ERR_NULL;
+    if (c1_below && (!stat_partial || !c2_below)) return PN2_ERR_NULL;
     const int P = pn2_mlp_bwd_layer_partials(M, N, K);
     if (P == 0) return PN2_ERR_UNSUPPORTED;
     bool ok = (ldg % 4 == 0) && (ldz % 4 == 0) && (ldw % 4 == 0) && (ldx % 4 == 0) && aligned16(g) && aligned16(z) &&
@@ -383,5 +385,8 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     PN2_FB(4, 1); PN2_FB(4, 2); PN2_FB(4, 4);
 #undef PN2_FB
     if (rc != PN2_OK) return rc;
+    if (c1_below)                                    // BatchNorm-backward constants of the layer below, same launch
+        return pn2::launch_bwd_post(dw_partial, P, N, K, dw, db, stat_partial, K, (double)M, dgamma_below, dbeta_below, c1_below,
+                                    c2_below, stream);
     return pn2::launch_dw_reduce(dw_partial, P, N, K, dw, db, stream);
 }

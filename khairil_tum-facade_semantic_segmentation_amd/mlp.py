@@ -152,6 +152,7 @@ class _MLPStack(torch.autograd.Function):
             _lib.check(rc, "pn2_bn_bwd_reduce")
             g = gy
             g_argk = argk
+            carried = None
             for l in range(L - 1, -1, -1):
                 w, b = params[4 * l], params[4 * l + 1]
                 Co = w.shape[0]
@@ -159,11 +160,15 @@ class _MLPStack(torch.autograd.Function):
                 Ci = w2.shape[1]
                 z = zs[l]
                 sc, sh, mu, istd = coefs[l]
-                dgamma, dbeta = torch.empty(Co, **f32), torch.empty(Co, **f32)
-                c1, c2 = torch.empty(Co, **f32), torch.empty(Co, **f32)
-                rc = lib.pn2_bn_bwd_finalize(_ptr(part), P, Co, float(M), _ptr(dgamma), _ptr(dbeta), _ptr(c1), _ptr(c2),
-                                             _stream(dev))
-                _lib.check(rc, "pn2_bn_bwd_finalize")
+                if carried is not None:                 # finalized in the launch that reduced the layer above's dW
+                    dgamma, dbeta, c1, c2 = carried
+                    carried = None
+                else:
+                    dgamma, dbeta = torch.empty(Co, **f32), torch.empty(Co, **f32)
+                    c1, c2 = torch.empty(Co, **f32), torch.empty(Co, **f32)
+                    rc = lib.pn2_bn_bwd_finalize(_ptr(part), P, Co, float(M), _ptr(dgamma), _ptr(dbeta), _ptr(c1), _ptr(c2),
+                                                 _stream(dev))
+                    _lib.check(rc, "pn2_bn_bwd_finalize")
                 if not ctx.training:                    # frozen statistics: dz = scale * gh, no batch terms
                     c1.zero_()
                     c2.zero_()
@@ -180,19 +185,23 @@ class _MLPStack(torch.autograd.Function):
                         xin, below = zs[l - 1], coefs[l - 1]
                         gp = torch.empty((M, Ci), **f32)
                         spart = torch.empty((Pf, 2, Ci), **f32)
+                        nxt = tuple(torch.empty(Ci, **f32) for _ in range(4))    # dgamma, dbeta, c1, c2 of layer l-1
                     else:
                         xin, below = x1, (None, None, None, None)
                         gp = torch.empty((M, Ci), **f32) if ctx.needs_input_grad[2] else None
                         spart = None
+                        nxt = (None, None, None, None)
                     rc = lib.pn2_mlp_bwd_layer(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(g_argk), pk, _ptr(sc), _ptr(sh),
                                                _ptr(mu), _ptr(istd), _ptr(c1), _ptr(c2), _ptr(w2), w2.stride(0), _ptr(xin),
                                                xin.stride(0), _ptr(below[0]), _ptr(below[1]), _ptr(below[2]), _ptr(below[3]),
                                                _ptr(gp), 0 if gp is None else gp.stride(0), _ptr(spart), _ptr(wpart), _ptr(dw),
-                                               _ptr(db), M, Co, Ci, _stream(dev))
+                                               _ptr(db), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), _ptr(nxt[3]), M, Co, Ci,
+                                               _stream(dev))
                     _lib.check(rc, "pn2_mlp_bwd_layer")
                     grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db
                     if l > 0:
                         g, g_argk, part, P = gp, None, spart, Pf
+                        carried = nxt
                     else:
                         gx1, gx2 = gp, None
                     continue

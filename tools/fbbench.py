@@ -44,7 +44,7 @@ def main():
             rc = lib.pn2_mlp_bwd_layer(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(argk), 32 if pooled else 0,
                                        *[_ptr(c) for c in cs], _ptr(w), w.stride(0), _ptr(x), x.stride(0),
                                        *[_ptr(b) for b in below], _ptr(gp), 0 if gp is None else gp.stride(0), _ptr(spart),
-                                       _ptr(wpart), _ptr(dw), _ptr(db), M, N, K, _stream(dev))
+                                       _ptr(wpart), _ptr(dw), _ptr(db), None, None, None, None, M, N, K, _stream(dev))
             assert rc == 0, rc
         for _ in range(3):
             run()
