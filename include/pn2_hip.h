@@ -180,6 +180,13 @@ int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ldz, const un
                       float *dgamma_below, float *dbeta_below, float *c1_below, float *c2_below, int M, int N, int K,
                       pn2_stream_t stream);
 
+/* The two reductions that follow a layer's backward in one launch: dw/db from dw_partial [P][N][K+1] (as the
+ * tail of pn2_mlp_dw, which leaves the slabs unreduced when called with dw = NULL) and pn2_bn_bwd_finalize of
+ * stat_partial [Ps][2][C] for the layer below. */
+int pn2_mlp_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial,
+                     int Ps, int C, double count, float *dgamma, float *dbeta, float *c1, float *c2,
+                     pn2_stream_t stream);
+
 /* BatchNorm+ReLU backward statistics of the top layer of a stack: partial
  * [pn2_bn_bwd_reduce_partials(rows)][2][C] sums of gh and gh*xh over rows (rows = M, or the
  * M/pool_k pooled rows with argk).  pn2_bn_bwd_finalize turns partials (from here or from the

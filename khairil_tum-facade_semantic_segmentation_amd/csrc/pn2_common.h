@@ -24,8 +24,8 @@ int tune_get(const char *name, int dflt);
 // (pn2_mlp.hip); shared by the weight-gradient launchers.
 int launch_dw_reduce(const float *partial, int P, int N, int K, float *dw, float *db, hipStream_t stream);
 // the same plus, in the same launch, the BatchNorm-backward finalize of stat_partial [P][2][C] (pn2_bn_bwd_finalize)
-int launch_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial, int C,
-                    double count, float *dgamma, float *dbeta, float *c1, float *c2, hipStream_t stream);
+int launch_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial, int Ps,
+                    int C, double count, float *dgamma, float *dbeta, float *c1, float *c2, hipStream_t stream);
 
 // |p|^2 exactly as torch.sum(p ** 2, -1) evaluates it: ((x*x + y*y) + z*z), every op rounded
 // (reference models/pointnet2_utils.py:38-39; rule SURVEY.md 8a-2).

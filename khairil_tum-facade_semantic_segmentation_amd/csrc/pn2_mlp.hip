@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
 // statistics of the layer below.
 __global__ __launch_bounds__(1024) void bwd_post_kernel(const float *__restrict__ dw_partial, int P, int N, int K,
                                                        float *__restrict__ dw, float *__restrict__ db, int nred,
-                                                       const float *__restrict__ stat_partial, int C, double count,
+                                                       const float *__restrict__ stat_partial, int Ps, int C, double count,
                                                        float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                        float *__restrict__ c1, float *__restrict__ c2)
 {
@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(1024) void bwd_post_kernel(const float *__restrict_
     if ((int)blockIdx.x < nred)
         dw_reduce_block(blockIdx.x, dw_partial, P, N, K, dw, db, reinterpret_cast<float (*)[33]>(sQ));
     else
-        bn_bwd_finalize_block(blockIdx.x - nred, stat_partial, P, C, count, dgamma, dbeta, c1, c2, sS, sQ);
+        bn_bwd_finalize_block(blockIdx.x - nred, stat_partial, Ps, C, count, dgamma, dbeta, c1, c2, sS, sQ);
 }
 
 inline unsigned grid_for(long long total, int threads)
@@ -1494,13 +1494,23 @@ int pn2::launch_dw_reduce(const float *partial, int P, int N, int K, float *dw, 
     return PN2_LAUNCH_RC();
 }
 
-int pn2::launch_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial, int C,
-                         double count, float *dgamma, float *dbeta, float *c1, float *c2, hipStream_t stream)
+int pn2::launch_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial, int Ps,
+                         int C, double count, float *dgamma, float *dbeta, float *c1, float *c2, hipStream_t stream)
 {
     const int nred = (N * (K + 1) + 31) / 32, nfin = (C + 31) / 32;
-    hipLaunchKernelGGL(bwd_post_kernel, dim3(nred + nfin), dim3(1024), 0, stream, dw_partial, P, N, K, dw, db, nred, stat_partial, C,
-                       count, dgamma, dbeta, c1, c2);
+    hipLaunchKernelGGL(bwd_post_kernel, dim3(nred + nfin), dim3(1024), 0, stream, dw_partial, P, N, K, dw, db, nred, stat_partial, Ps,
+                       C, count, dgamma, dbeta, c1, c2);
     return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_mlp_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial,
+                                int Ps, int C, double count, float *dgamma, float *dbeta, float *c1, float *c2,
+                                pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(dw_partial); PN2_REQUIRE_PTR(dw); PN2_REQUIRE_PTR(stat_partial); PN2_REQUIRE_PTR(c1); PN2_REQUIRE_PTR(c2);
+    if (P <= 0 || N <= 0 || K <= 0 || Ps <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
+    return pn2::launch_bwd_post(dw_partial, P, N, K, dw, db, stat_partial, Ps, C, count, dgamma, dbeta, c1, c2,
+                                static_cast<hipStream_t>(stream));
 }
 
 PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, const unsigned char *argk, int pool_k,
@@ -1519,7 +1529,6 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     PN2_REQUIRE_PTR(c2);
     PN2_REQUIRE_PTR(x1);
     PN2_REQUIRE_PTR(partial);
-    PN2_REQUIRE_PTR(dw);
     if (M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !x2) || (argk && pool_k <= 0)) return PN2_ERR_SHAPE;
     if ((ascale == nullptr) != (ashift == nullptr)) return PN2_ERR_NULL;
     DwArgs a;
@@ -1546,7 +1555,7 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
         hipLaunchKernelGGL(mlp_dw_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
     }
     int rc = PN2_LAUNCH_RC();
-    if (rc != PN2_OK) return rc;
+    if (rc != PN2_OK || dw == nullptr) return rc;         // dw NULL: slabs only, reduced later by pn2_mlp_bwd_post
     const int total = N * (K + 1);
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(1024), 0, stream, partial, P, N, K, dw, db);
     return PN2_LAUNCH_RC();

@@ -386,7 +386,7 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
 #undef PN2_FB
     if (rc != PN2_OK) return rc;
     if (c1_below)                                    // BatchNorm-backward constants of the layer below, same launch
-        return pn2::launch_bwd_post(dw_partial, P, N, K, dw, db, stat_partial, K, (double)M, dgamma_below, dbeta_below, c1_below,
+        return pn2::launch_bwd_post(dw_partial, P, N, K, dw, db, stat_partial, P, K, (double)M, dgamma_below, dbeta_below, c1_below,
                                     c2_below, stream);
     return pn2::launch_dw_reduce(dw_partial, P, N, K, dw, db, stream);
 }

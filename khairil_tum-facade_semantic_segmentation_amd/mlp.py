@@ -219,10 +219,13 @@ class _MLPStack(torch.autograd.Function):
                     dw_stream = side.cuda_stream
                 else:
                     dw_stream = _stream(dev)
+                # with a layer below and no side stream, the slabs stay unreduced here and are summed in the launch
+                # that also finalizes the statistics the dX GEMM is about to produce (pn2_mlp_bwd_post)
+                defer = l > 0 and side is None
                 rc = lib.pn2_mlp_dw(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(g_argk), pool_k if g_argk is not None else 0,
                                     _ptr(sc), _ptr(sh), _ptr(mu), _ptr(istd), _ptr(c1), _ptr(c2), _ptr(a1), a1.stride(0), ak1,
                                     _ptr(a2), 0 if a2 is None else a2.stride(0), ak2, _ptr(asc), _ptr(ash), M, Co, _ptr(wpart),
-                                    _ptr(dw), _ptr(db), dw_stream)
+                                    None if defer else _ptr(dw), _ptr(db), dw_stream)
                 _lib.check(rc, "pn2_mlp_dw")
                 grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db
                 # dX (= gradient w.r.t. the activation below), masked + reduced for the layer below
@@ -234,6 +237,12 @@ class _MLPStack(torch.autograd.Function):
                     part = torch.empty((P, 2, Ci), **f32)
                     _gemm(lib, dev, g, Co, z, Co, PRO_BN_BWD, consts, g_argk, pool_k if g_argk is not None else 0, w2,
                           w2.stride(0), 1, None, gp, M, Ci, part, (zp, psc, psh, pmu, pistd))
+                    if defer:
+                        carried = tuple(torch.empty(Ci, **f32) for _ in range(4))
+                        rc = lib.pn2_mlp_bwd_post(_ptr(wpart), Pw, Co, Ci, _ptr(dw), _ptr(db), _ptr(part), P, Ci, float(M),
+                                                  _ptr(carried[0]), _ptr(carried[1]), _ptr(carried[2]), _ptr(carried[3]),
+                                                  _stream(dev))
+                        _lib.check(rc, "pn2_mlp_bwd_post")
                     g, g_argk = gp, None
                 else:
                     gx1 = gx2 = None
