@@ -495,10 +495,15 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
 // take one 32-column block each and share the A rows.  Used when M is so small (deep levels:
 // M = 1024..8192) that 128-row tiles would leave most of the 256 CUs idle.  Same prologues,
 // epilogues, statistics and double-buffered staging as mlp_gemm_pipe_kernel.
-template <int PRO, bool WT>
-__global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p, int pool_shift)
+// BM = 64: eight waves, 2 row slices x 4 column blocks: half the weight-tile traffic per flop, for shapes
+// that still give every CU a workgroup with 64-row tiles.
+template <int PRO, bool WT, int BM>
+__global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int pool_shift)
 {
-    constexpr int BN = 128, BM = 32;
+    constexpr int BN = 128;
+    constexpr int T = 8 * BM;                         // threads: one float4 of the A chunk each
+    constexpr int RS = BM / 32;                       // 32-row slices
+    constexpr int NBI = (BN * 8) / T;                 // B float4 per thread and chunk
     constexpr int LDBT = BN + 4;
     constexpr int SB_ELEMS = WT ? MLP_BK * LDBT : BN * MLP_LD;
     constexpr int SA_ELEMS = BM * MLP_LD;
@@ -512,9 +517,10 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int nsteps = my_tiles * nk;
     const bool bwd_epi = p.mask_z != nullptr;
-    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: row ar (0..31), 4 columns at ac4
+    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: row ar (0..BM-1), 4 columns at ac4
+    const int rw = wave % RS, cw = wave / RS;               // this wave's row slice / 32-column block
 
-    float4 ra, rz, rb[4];
+    float4 ra, rz, rb[NBI];
     uchar4 rk;
     float4 cs, ch, cm, ci, cc1, cc2;
     ra = rz = cs = ch = cm = ci = cc1 = cc2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -554,8 +560,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * MLP_THREADS;
+        for (int i = 0; i < NBI; ++i) {
+            const int e = tid + i * T;
             rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!WT) {
                 const int r = e >> 3, c4 = (e & 7) * 4;
@@ -597,8 +603,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
         }
         *reinterpret_cast<float4 *>(&sA[ar * MLP_LD + ac4]) = v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * MLP_THREADS;
+        for (int i = 0; i < NBI; ++i) {
+            const int e = tid + i * T;
             if (!WT) {
                 const int r = e >> 3, c4 = (e & 7) * 4;
                 *reinterpret_cast<float4 *>(&sB[r * MLP_LD + c4]) = rb[i];
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int col = col0 + wave * 32 + l31;                  // this lane's output column
+    const int col = col0 + cw * 32 + l31;                    // this lane's output column
 
     if (nsteps > 0) {
         issue(0);
@@ -624,15 +630,15 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
         if (step + 1 < nsteps) issue(step + 1);
         const float *sA = sAbuf + (step & 1) * SA_ELEMS;
         const float *sB = sBbuf + (step & 1) * SB_ELEMS;
-        const float *aRow = &sA[l31 * MLP_LD + 16 * half];
+        const float *aRow = &sA[(rw * 32 + l31) * MLP_LD + 16 * half];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
             float4 b4;
             if (!WT) {
-                b4 = *reinterpret_cast<const float4 *>(&sB[(wave * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
+                b4 = *reinterpret_cast<const float4 *>(&sB[(cw * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
             } else {
-                const float *bp = &sB[(16 * half + 4 * q) * LDBT + wave * 32 + l31];
+                const float *bp = &sB[(16 * half + 4 * q) * LDBT + cw * 32 + l31];
                 b4 = make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
         }
         const int t = step / nk, kc = step - t * nk;
         if (kc == nk - 1) {
-            const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM;
+            const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM + rw * 32;
             if (col < p.N) {
                 const float bv = p.bias ? p.bias[col] : 0.f;
                 float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
@@ -682,9 +688,10 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_rows32_kernel(GemmArgs p
     if (!p.stat_partial) return;
     const float s = csum + __shfl_xor(csum, 32);
     const float q = csq + __shfl_xor(csq, 32);
-    if (half == 0 && col < p.N) {                             // every wave owns its own 32 columns
-        p.stat_partial[((size_t)blockIdx.x * 2 + 0) * p.N + col] = s;
-        p.stat_partial[((size_t)blockIdx.x * 2 + 1) * p.N + col] = q;
+    if (half == 0 && col < p.N) {                             // every wave owns its own 32 rows x 32 columns
+        const size_t prow = (size_t)blockIdx.x * RS + rw;     // RS partial rows per workgroup
+        p.stat_partial[(prow * 2 + 0) * p.N + col] = s;
+        p.stat_partial[(prow * 2 + 1) * p.N + col] = q;
     }
 }
 
@@ -1403,7 +1410,13 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
             int pool_shift = -1;
             if (a.argk && (a.pool_k & (a.pool_k - 1)) == 0) { pool_shift = 0; while ((1 << pool_shift) < a.pool_k) ++pool_shift; }
             dim3 grid((unsigned)gx, (unsigned)((N + 127) / 128));
-#define PN2_R32(P, W) hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W>), grid, dim3(MLP_THREADS), 0, stream, a, pool_shift)
+            // 64-row tiles (statistics: two partial rows per workgroup, so half as many workgroups) when that
+            // still covers the CUs
+            const long long wgs64 = (long long)((M + 63) / 64) * ((N + 127) / 128);
+            const bool rows64 = (gx % 2 == 0) && wgs64 >= pn2::tune_get("mlp_rows64_min_wgs", 256) && pn2::tune_get("mlp_rows64", 1);
+            if (rows64) grid.x = (unsigned)(gx / 2);
+#define PN2_R32(P, W) do { if (rows64) hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 64>), grid, dim3(512), 0, stream, a, pool_shift); \
+                           else hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 32>), grid, dim3(256), 0, stream, a, pool_shift); } while (0)
             if (prologue == PRO_NONE) { if (a.wt) PN2_R32(PRO_NONE, true); else PN2_R32(PRO_NONE, false); }
             else if (prologue == PRO_BN_RELU) { if (a.wt) PN2_R32(PRO_BN_RELU, true); else PN2_R32(PRO_BN_RELU, false); }
             else { if (a.wt) PN2_R32(PRO_BN_BWD, true); else PN2_R32(PRO_BN_BWD, false); }
