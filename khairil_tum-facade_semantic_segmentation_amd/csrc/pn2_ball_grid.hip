@@ -282,36 +282,44 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     }
     if (!grouped) return;
     // ---- (9) grouped rows [xyz - centroid, feats] of this centroid: K rows of qpr float4, contiguous;
-    //      lane l16 writes float4 number l16 + 16 i, 4 of them in flight ------------------------------
+    //      lane l16 writes float4 number l16 + 16 i ------------------------------------------------------
     const int Cg = 3 + D;
     const int qpr = Cg >> 2;
     const int E = K * qpr;
     const float *bp = points ? points + (size_t)b * N * D : nullptr;
     float4 *g4 = reinterpret_cast<float4 *>(grouped + ((size_t)b * S + my_s) * (size_t)K * ldg);
-    for (int e0 = l16; e0 < E; e0 += 4 * 16) {
-        float4 v[4];
+    // Branch-free gathers (a load under a divergent branch is waited for at the end of the branch, which
+    // would serialise them): every element is one 16-byte load (xyz through the same path: 4 floats that
+    // contain the point's 3) plus the row's first feature, 6 elements in flight per lane.
+    constexpr int U = 6;
+    for (int e0 = l16; e0 < E; e0 += U * 16) {
+        f32x4u f[U];
+        float f0[U];
+        int part[U], shift[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * 16;
-            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (e < E && n > 0) {
-                const int k = qpr == 1 ? e : (int)__umulhi((unsigned)e, ldg_magic);         // e / qpr
-                const int part = e - k * qpr;
-                const int j = oi[k < n ? k : 0];
-                const float *row = bp + (size_t)j * D;
-                if (part == 0) {
-                    const f32x3u p3 = *reinterpret_cast<const f32x3u *>(bx + (size_t)j * 3);
-                    v[u] = make_float4(p3.x - cx, p3.y - cy, p3.z - cz, D > 0 ? row[0] : 0.0f);          // :128, :131
-                } else {
-                    const f32x4u f = *reinterpret_cast<const f32x4u *>(row + (4 * part - 3));
-                    v[u] = make_float4(f.x, f.y, f.z, f.w);
-                }
-            }
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u * 16, E - 1);
+            const int k = qpr == 1 ? e : (int)__umulhi((unsigned)e, ldg_magic);             // e / qpr
+            part[u] = e - k * qpr;
+            const int j = n > 0 ? (int)oi[k < n ? k : 0] : 0;
+            const float *row = bp ? bp + (size_t)j * D : bx;
+            shift[u] = (j == N - 1) ? 1 : 0;                      // the last point is read as [.., x, y, z]
+            const float *src = part[u] == 0 ? bx + (size_t)j * 3 - shift[u] : row + (4 * part[u] - 3);
+            f[u] = *reinterpret_cast<const f32x4u *>(src);
+            f0[u] = row[0];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int e = e0 + u * 16;
-            if (e < E) g4[e] = v[u];
+            if (e < E) {
+                float4 v = make_float4(f[u].x, f[u].y, f[u].z, f[u].w);
+                if (part[u] == 0) {
+                    const float x = shift[u] ? f[u].y : f[u].x, y = shift[u] ? f[u].z : f[u].y, z = shift[u] ? f[u].w : f[u].z;
+                    v = make_float4(x - cx, y - cy, z - cz, D > 0 ? f0[u] : 0.0f);           // :128, :131
+                }
+                if (n <= 0) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                g4[e] = v;
+            }
         }
     }
 }
