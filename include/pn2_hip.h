@@ -198,6 +198,11 @@ int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long lon
 int pn2_bn_bwd_finalize(const float *partial, int P, int C, double count, float *dgamma, float *dbeta,
                         float *c1, float *c2, pn2_stream_t stream);
 
+/* dst[r][c] = c < cols_src ? src[r][c] : 0, c < cols_dst, r < rows (pitches lds, ldd): pads the first conv weight of
+ * a stack to the 16-byte aligned row width of its input, and slices its gradient back (cols_dst < cols_src). */
+int pn2_copy_pad_cols(const float *src, int lds, int cols_src, float *dst, int ldd, int cols_dst, long long rows,
+                      pn2_stream_t stream);
+
 /* ---- transposed index tables: atomic-free, order-fixed backward of the gather operators ---------------
  * The autograd of index_points / grouping (models/pointnet2_utils.py:43-60, :127-132) and of the 3-NN
  * interpolation (:296-303) is a scatter-add through idx.  pn2_invert_index turns idx [B][E] (values in

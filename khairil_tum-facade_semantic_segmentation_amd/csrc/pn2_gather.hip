@@ -51,6 +51,18 @@ __global__ __launch_bounds__(256) void index_points_backward_kernel(const float 
     }
 }
 
+// dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (row pitches lds / ldd): zero-padding of a weight's
+// columns to the padded row width of its input, and (cols_dst < cols_src) the slice back for the gradient.
+__global__ __launch_bounds__(256) void copy_pad_cols_kernel(const float *__restrict__ src, int lds, int cols_src,
+                                                            float *__restrict__ dst, int ldd, int cols_dst, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long long r = t / cols_dst;
+    const int c = (int)(t - r * cols_dst);
+    dst[r * ldd + c] = c < cols_src ? src[r * lds + c] : 0.0f;
+}
+
 // One centroid's [K, 3+D] block per blockIdx.x, 256 consecutive elements per blockIdx.y: all
 // index arithmetic is 32-bit (a magic multiply for f / Cg), every gather independent.
 __global__ __launch_bounds__(256) void group_points_kernel(const float *__restrict__ xyz,
@@ -144,6 +156,20 @@ PN2_EXPORT int pn2_index_points_backward(const float *grad_out, const int64_t *i
     hipLaunchKernelGGL(index_points_backward_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream_), grad_out, idx, total, N, D, (long long)M, Cg, col0,
                        grad_points);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_copy_pad_cols(const float *src, int lds, int cols_src, float *dst, int ldd, int cols_dst, long long rows,
+                                 pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(src);
+    PN2_REQUIRE_PTR(dst);
+    if (rows < 0 || cols_src <= 0 || cols_dst <= 0 || lds < cols_src || ldd < cols_dst) return PN2_ERR_SHAPE;
+    const long long total = rows * cols_dst;
+    if (total == 0) return PN2_OK;
+    if ((total + 255) / 256 > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(copy_pad_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), src,
+                       lds, cols_src, dst, ldd, cols_dst, total);
     return PN2_LAUNCH_RC();
 }
 

@@ -261,6 +261,34 @@ class _MLPStack(torch.autograd.Function):
         return (None, None, gx1, gx2) + tuple(grads)
 
 
+class _PadCols(torch.autograd.Function):
+    """w [Co, cin] -> [Co, kin] with zero columns behind cin (one launch; F.pad and its backward cost five)."""
+
+    @staticmethod
+    def forward(ctx, w, kin):
+        dev = _dev(w)
+        lib = _lib.load()
+        Co, cin = w.shape
+        out = torch.empty((Co, kin), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_copy_pad_cols(_ptr(w), w.stride(0), cin, _ptr(out), kin, kin, Co, _stream(dev))
+        _lib.check(rc, "pn2_copy_pad_cols")
+        ctx.cin = cin
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dev = g.device
+        lib = _lib.load()
+        g = g.contiguous()
+        Co, kin = g.shape
+        out = torch.empty((Co, ctx.cin), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pn2_copy_pad_cols(_ptr(g), kin, kin, _ptr(out), ctx.cin, ctx.cin, Co, _stream(dev))
+        _lib.check(rc, "pn2_copy_pad_cols")
+        return out, None
+
+
 def mlp_stack(x1, x2, convs, bns, pool_k=0):
     """Run [conv -> bn -> relu] x len(convs) on rows [x1 | x2] ([M,K1], [M,K2] or None); with
     pool_k > 0 the output is max-pooled over groups of pool_k consecutive rows."""
@@ -286,6 +314,6 @@ def mlp_stack(x1, x2, convs, bns, pool_k=0):
                 raise ValueError("input rows have %d columns, first conv expects %d" % (kin, cin))
             w = w.reshape(w.shape[0], cin)
             if kin > cin:
-                w = torch.nn.functional.pad(w, (0, kin - cin))
+                w = _PadCols.apply(w.contiguous(), kin)
         params += [w, conv.bias, bn.weight, bn.bias]
     return _MLPStack.apply(list(bns), pool_k, x1, x2, *params)
