@@ -831,7 +831,7 @@ constexpr int DW_BN = 64, DW_BK = 64, DW_LD = 68;
 // VEC4: every row pitch / column split is a multiple of 4 floats and 16-B aligned, so a thread
 // owns 4 fixed columns (its BatchNorm constants live in registers for the whole kernel) and
 // stages 8 rows of them per tile with float4 loads, all issued before the first is consumed.
-template <bool VEC4>
+template <bool VEC4, bool POOLED>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 {
     __shared__ __attribute__((aligned(16))) float sD[MLP_BM * DW_LD];     // dz tile   [128 m][64 n]
@@ -873,28 +873,26 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 
     float4 gv[8], zv[8], xv[8];
     uchar4 av[8];
-    // VEC4: global loads of a tile into registers (issued one tile ahead of their use)
+    // VEC4: global loads of a tile into registers (issued one tile ahead of their use).  Unconditional
+    // (clamped addresses; rows / columns outside the problem are masked when the values are consumed): a
+    // load under a divergent branch is waited for at the end of the branch, which serialised the 8 passes.
+    const int n4c = n_ok ? n4 : 0, k4c = k_act ? k4 : 0;
+    const float *xsrc = from1 ? p.x1 : (p.x2 ? p.x2 : p.x1);
+    const int xld = from1 ? p.ld1 : (p.x2 ? p.ld2 : p.ld1), xcol = k_act ? (from1 ? k4 : k4 - p.K1) : 0;
     auto issue = [&](int tile) {
         const int row0 = tile * MLP_BM;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = row0 + rb + 16 * i;
-            const bool rok = row < p.M;
-            gv[i] = zv[i] = xv[i] = make_float4(0, 0, 0, 0);
-            av[i] = make_uchar4(255, 255, 255, 255);
-            if (rok && n_ok) {
-                if (p.argk) {
-                    const int cent = row / p.pool_k;
-                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4);
-                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4);
-                } else {
-                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4);
-                }
-                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4);
+            const int row = min(row0 + rb + 16 * i, p.M - 1);
+            if (POOLED) {                             // g / argk per centroid
+                const int cent = row / p.pool_k;
+                gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4c);
+                av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4c);
+            } else {
+                gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4c);
             }
-            if (rok && k_act)
-                xv[i] = from1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k4)
-                              : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k4 - p.K1));
+            zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4c);
+            xv[i] = *reinterpret_cast<const float4 *>(xsrc + (size_t)row * xld + xcol);
         }
     };
     if (VEC4 && (int)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -910,7 +908,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
                 if (row < p.M) {
                     if (n_ok) {
                         float4 g = gv[i];
-                        if (p.argk) {
+                        if (POOLED) {
                             const int kk = row % p.pool_k;
                             g.x = av[i].x == kk ? g.x : 0.f;
                             g.y = av[i].y == kk ? g.y : 0.f;
@@ -1031,6 +1029,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 // tiles are re-staged only N/128 resp. K/128 times.
 constexpr int DW2_ROWS = 64, DW2_LD = 132;
 
+template <bool POOLED>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
 {
     __shared__ __attribute__((aligned(16))) float sD[DW2_ROWS * DW2_LD];   // dz tile  [64 m][128 n]
@@ -1068,27 +1067,24 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
     }
     float4 gv[8], zv[8], xv[8];
     uchar4 av[8];
+    // unconditional loads (clamped addresses, masked when consumed), see mlp_dw_kernel
+    const int n4c = n_ok ? n4 : 0;
+    const float *xsrc = from1 ? p.x1 : (p.x2 ? p.x2 : p.x1);
+    const int xld = from1 ? p.ld1 : (p.x2 ? p.ld2 : p.ld1), xcol = k_act ? (from1 ? k4 : k4 - p.K1) : 0;
     auto issue = [&](int tile) {
         const int row0 = tile * DW2_ROWS;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = row0 + rb + 8 * i;
-            const bool rok = row < p.M;
-            gv[i] = zv[i] = xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            av[i] = make_uchar4(255, 255, 255, 255);
-            if (rok && n_ok) {
-                if (p.argk) {
-                    const int cent = row / p.pool_k;
-                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4);
-                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4);
-                } else {
-                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4);
-                }
-                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4);
+            const int row = min(row0 + rb + 8 * i, p.M - 1);
+            if (POOLED) {
+                const int cent = row / p.pool_k;
+                gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4c);
+                av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4c);
+            } else {
+                gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4c);
             }
-            if (rok && k_act)
-                xv[i] = from1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k4)
-                              : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k4 - p.K1));
+            zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4c);
+            xv[i] = *reinterpret_cast<const float4 *>(xsrc + (size_t)row * xld + xcol);
         }
     };
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -1106,7 +1102,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
             if (row < p.M) {
                 if (n_ok) {
                     float4 g = gv[i];
-                    if (p.argk) {
+                    if (POOLED) {
                         const int kk = row % p.pool_k;
                         g.x = av[i].x == kk ? g.x : 0.f;
                         g.y = av[i].y == kk ? g.y : 0.f;
@@ -1560,12 +1556,14 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     if (vec4 && N >= 128 && K >= 128 && pn2::tune_get("mlp_dw128", 0)) {   // measured: no gain over the 64x64 form
         grid.y = (unsigned)((N + 127) / 128);
         grid.z = (unsigned)((K + 127) / 128);
-        hipLaunchKernelGGL(mlp_dw128_kernel, grid, dim3(MLP_THREADS), 0, stream, a);
+        if (argk) hipLaunchKernelGGL(mlp_dw128_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL(mlp_dw128_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
     } else if (vec4) {
         grid.z = (unsigned)((K + DW_BK - 1) / DW_BK);             // the bias column is summed on the side
-        hipLaunchKernelGGL(mlp_dw_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
+        if (argk) hipLaunchKernelGGL((mlp_dw_kernel<true, true>), grid, dim3(MLP_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((mlp_dw_kernel<true, false>), grid, dim3(MLP_THREADS), 0, stream, a);
     } else {
-        hipLaunchKernelGGL(mlp_dw_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
+        hipLaunchKernelGGL((mlp_dw_kernel<false, false>), grid, dim3(MLP_THREADS), 0, stream, a);
     }
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK || dw == nullptr) return rc;         // dw NULL: slabs only, reduced later by pn2_mlp_bwd_post
