@@ -1480,11 +1480,11 @@ PN2_EXPORT int pn2_bn_relu_out(const float *z, long long rows_out, int C, int po
 
 PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
 {
-    // ~1024 workgroups in flight: the M axis is split so that (M slabs) x (64x64 output blocks) ~ 1024
+    // ~512 workgroups in flight (2 per CU): the M axis is split so that (M slabs) x (64x64 output blocks) ~ 512
     const bool wide = N >= 128 && K >= 128 && pn2::tune_get("mlp_dw128", 0);
     const int ntiles = wide ? (M + DW2_ROWS - 1) / DW2_ROWS : (M + MLP_BM - 1) / MLP_BM;
     const int blocks = wide ? ((N + 127) / 128) * ((K + 127) / 128) : ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK);
-    int p = 1024 / (blocks < 1 ? 1 : blocks);
+    int p = pn2::tune_get("dw_wgs", 512) / (blocks < 1 ? 1 : blocks);      // 256/384/640/1024 measured slower
     // (a cap tying the partial-slab traffic to the layer's input traffic was measured: no gain)
     const int div = pn2::tune_get("dw_p_div", 0);
     if (div > 0) {
