@@ -67,3 +67,28 @@ def test_precomputed_geometry_is_identical(monkeypatch):
         geo = model.compute_geometry(xs[1])
         b, b4 = model(xs[1], geometry=geo)
     assert torch.equal(a, b) and torch.equal(a4, b4)
+
+
+def test_prepare_captures_without_touching_the_model(monkeypatch):
+    """SemSegTrainer.prepare() (graph capture before the first collective) must leave parameters, BatchNorm
+    buffers and the Adam state as if nothing had run, and the steps after it must train like eager steps."""
+    torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
+    from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
+    steps = 4
+    ref = _train(torch, xs, ys, cw, fresh_model(), steps, graphs=False, prefetch_geometry=False)
+    model = fresh_model()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tr = SemSegTrainer(model, class_weight=cw, graphs=True, prefetch_geometry=True, graph_warmup=2)
+    tr.prepare(xs[0], ys[0])
+    torch.cuda.synchronize()
+    assert tr._g_fwd_bwd is not None
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for st in tr.optimizer.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                assert float(v.abs().max()) == 0.0
+    got = np.array([float(tr.step(xs[i % 2], ys[i % 2], xs[(i + 1) % 2])) for i in range(steps)])
+    assert abs(got[0] - ref[0]) <= 1e-4
+    np.testing.assert_allclose(got, ref, rtol=2e-2)
+    assert int(model.sa1.mlp_bns[0].num_batches_tracked) == steps
