@@ -240,6 +240,15 @@ int pn2_nll_loss(const float *logp, const int64_t *target, const float *weight, 
 int pn2_nll_loss_backward(const float *gloss, const int64_t *target, const float *weight, const float *wsum,
                           long long M, int C, long long ignore_index, float *glogp, pn2_stream_t stream);
 
+/* ---- optimiser of the reference loop on one flat buffer ------------------------------------------------
+ * torch.optim.Adam(lr, betas, eps, weight_decay) (sem_seg_training.py:576-582) over n fp32 parameters that are
+ * views of `param`, gradients packed in `grad` (multiplied by grad_scale first: 1/world after an all-reduce sum).
+ * lr [1] and state [3] (step count, 1-beta1^t, sqrt(1-beta2^t); zero-initialised) live on the device, so the two
+ * launches can be replayed from a hipGraph. */
+int pn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const float *lr,
+                  float *state, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                  pn2_stream_t stream);
+
 /* ---- whole-scene inference aggregation --------------------------------------
  * add_vote(vote_label_pool, point_idx, pred_label, weight)            localfunctions.py:339-346
  * vote_pool[P][C] int32 += 1 at (point_idx[m], label[m]) for every m < M whose weight is neither 0

@@ -43,6 +43,7 @@ class FlatGradients:
         # None, not zeros: autograd then assigns each gradient instead of launching an add per parameter
         for p in self.params:
             p.grad = None
+        self.buffer = None
 
     def pack(self):
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
@@ -66,6 +67,49 @@ class FlatGradients:
         flat.div_(world)
 
 
+class FlatAdam:
+    """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-08, weight_decay) of the reference loop
+    (sem_seg_training.py:576-582) as ONE elementwise pass (pn2_adam_step): the parameters become views of one
+    flat buffer (same order as FlatGradients packs their gradients), the moments, the step counter and the
+    learning rate live on the device (hipGraph replay).  HIP device only."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        from . import _lib
+        self._lib = _lib
+        self.params = list(params)
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                view = self.flat[off:off + k].view_as(p)
+                view.copy_(p)
+                p.data = view
+                off += k
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.state = torch.zeros(3, dtype=torch.float32, device=dev)      # step, 1-beta1^t, sqrt(1-beta2^t)
+        self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+
+    def set_lr(self, lr):
+        """New learning rate (the reference re-sets param_group['lr'] every epoch, localfunctions.py:187-190);
+        a device scalar, so captured graphs pick it up."""
+        self.lr.fill_(float(lr))
+
+    def step(self, flat_grad, grad_scale=1.0):
+        lib = self._lib.load()
+        dev = self.flat.device
+        with torch.cuda.device(dev):
+            rc = lib.pn2_adam_step(self.flat.data_ptr(), flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                   self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr.data_ptr(), self.state.data_ptr(),
+                                   self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
+                                   torch.cuda.current_stream(dev).cuda_stream)
+        self._lib.check(rc, "pn2_adam_step")
+
+
 class SemSegTrainer:
     """graphs=True (HIP device only): the step is captured into hipGraphs after a few eager
     warm-up steps and replayed -- one graph for zero_grad+forward+loss+backward(+gradient
@@ -83,8 +127,11 @@ class SemSegTrainer:
         self.criterion = get_loss()
         on_gpu = next(model.parameters()).is_cuda
         self.graphs = bool(graphs) and on_gpu
-        self.optimizer = torch.optim.Adam(self.grads.params, lr=lr, betas=(0.9, 0.999), eps=1e-8,
-                                          weight_decay=weight_decay, fused=on_gpu, capturable=self.graphs)
+        # HIP device: one flat Adam pass over the packed gradients; CPU (tests of the exchange): torch's Adam
+        self.flat_adam = FlatAdam(self.grads.params, lr=lr, betas=(0.9, 0.999), eps=1e-8,
+                                  weight_decay=weight_decay) if on_gpu else None
+        self.optimizer = None if on_gpu else torch.optim.Adam(self.grads.params, lr=lr, betas=(0.9, 0.999), eps=1e-8,
+                                                              weight_decay=weight_decay)
         # prefetch_geometry: the FPS / ball-query / 3-NN pyramid of the NEXT batch (a function of
         # its coordinates only) is computed on a side stream while this batch's MLP work runs:
         # FPS is a latency-bound chain that occupies 16 of 256 CUs.
@@ -109,7 +156,7 @@ class SemSegTrainer:
     def prepare(self, blocks_cf, target):
         """Capture the hipGraphs NOW, without changing the model: `graph_warmup` dry forward/backward
         passes (allocator and lazy initialisations settle; BatchNorm buffers are restored afterwards, no
-        optimizer step), the Adam state created and zeroed, then the capture.
+        optimizer step), then the capture.
 
         Why: graphs captured while an RCCL communicator exists replay 9 % slower on this stack (measured on
         MI355X, ROCm 7.2: 3.43 -> 3.73 ms; the communicator's streams change how the graph's kernels are
@@ -122,18 +169,6 @@ class SemSegTrainer:
         saved = [b.detach().clone() for b in self.model.buffers()]
         for _ in range(max(1, self._graph_warmup)):
             self._forward_backward(blocks_cf, target)
-        # optimizer state must exist before capture (its lazy initialisation would otherwise be replayed);
-        # with lr = 0 the step leaves the parameters untouched, then the moments and the counter go back to 0
-        lrs = [g["lr"] for g in self.optimizer.param_groups]
-        for g in self.optimizer.param_groups:
-            g["lr"] = 0.0
-        self.optimizer.step()
-        for g, lr in zip(self.optimizer.param_groups, lrs):
-            g["lr"] = lr
-        for st in self.optimizer.state.values():
-            for v in st.values():
-                if torch.is_tensor(v):
-                    v.zero_()
         with torch.no_grad():
             for b, s in zip(self.model.buffers(), saved):
                 b.copy_(s)
@@ -163,12 +198,31 @@ class SemSegTrainer:
                 geo = self.model.compute_geometry(next_blocks_cf)
         return geo
 
+    def _pack_geometry(self, geo):
+        """The pyramid's tensors as one uint8 buffer (segment layout fixed at capture time)."""
+        parts = []
+        for t, pad in zip(geo, self._geo_pads):
+            if t is not None:
+                parts.append(t.contiguous().view(-1).view(torch.uint8))
+            if pad is not None:
+                parts.append(pad)
+        return torch.cat(parts)
+
     def _forward_backward(self, blocks_cf, target, geometry=None):
         self.grads.zero()
         pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
         loss = self.criterion(pred.reshape(-1, pred.shape[-1]), target.reshape(-1), None, self.class_weight)
         loss.backward()
         return loss.detach()
+
+    def _optimizer_step(self, grad_scale=1.0):
+        if self.flat_adam is not None:
+            if self.grads.buffer is None:
+                self.grads.pack()
+            self.flat_adam.step(self.grads.buffer, grad_scale)
+            self.grads.buffer = None
+        else:
+            self.optimizer.step()
 
     def _eager_step(self, blocks_cf, target, next_blocks_cf=None):
         geo = None
@@ -184,8 +238,8 @@ class SemSegTrainer:
                 if t is not None:
                     t.record_stream(self._side)
         loss = self._forward_backward(blocks_cf, target, geo)
-        self.grads.all_reduce_mean(self.group)
-        self.optimizer.step()
+        self.grads.all_reduce_mean(self.group)          # packs (grads.buffer) when there is an exchange
+        self._optimizer_step()
         return loss
 
     def _capture(self, blocks_cf, target):
@@ -199,7 +253,25 @@ class SemSegTrainer:
             self._static_next_x = blocks_cf.clone()
             torch.cuda.current_stream().wait_stream(self._side)
             with torch.no_grad():
-                self._geo_cur = [None if t is None else t.clone() for t in self.model.compute_geometry(self._static_x)]
+                first = self.model.compute_geometry(self._static_x)
+            # all pyramid tensors live in ONE byte buffer (16-byte aligned segments), so the hand-over after
+            # backward is a single copy instead of one small copy kernel per tensor (24 x 4 us on the step's tail)
+            self._geo_pads, off = [], 0
+            for t in first:
+                nbytes = 0 if t is None else t.numel() * t.element_size()
+                pad = (-nbytes) % 16
+                self._geo_pads.append(torch.zeros(pad, dtype=torch.uint8, device=blocks_cf.device) if pad else None)
+                off += nbytes + pad
+            self._geo_flat = torch.empty(off, dtype=torch.uint8, device=blocks_cf.device)
+            self._geo_flat.copy_(self._pack_geometry(first))
+            self._geo_cur, off = [], 0
+            for t, padt in zip(first, self._geo_pads):
+                if t is None:
+                    self._geo_cur.append(None)
+                    continue
+                nbytes = t.numel() * t.element_size()
+                self._geo_cur.append(self._geo_flat[off:off + nbytes].view(t.dtype).view(t.shape))
+                off += nbytes + (0 if padt is None else padt.numel())
             torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
@@ -207,24 +279,24 @@ class SemSegTrainer:
             geo = new_geo = None
             if self.prefetch:
                 new_geo = self._launch_prefetch(self._static_next_x)      # fork: side branch of the graph
+                with torch.cuda.stream(self._side):
+                    new_flat = self._pack_geometry(new_geo)
                 geo = self._geo_cur
             self._static_loss = self._forward_backward(self._static_x, self._static_y, geo)
             if self.prefetch:
                 self._side.wait_stream(torch.cuda.current_stream())       # backward no longer reads `cur`
                 with torch.cuda.stream(self._side):
-                    for cur, new in zip(self._geo_cur, new_geo):
-                        if cur is not None:
-                            cur.copy_(new)
-            if exchange:
-                self.grads.pack()                       # .grad become views of one flat buffer
-            else:
-                self.optimizer.step()
+                    self._geo_flat.copy_(new_flat)
+            flat = self.grads.pack()                    # .grad become views of one flat buffer
+            if not exchange:
+                self.flat_adam.step(flat)
             if self.prefetch:
                 torch.cuda.current_stream().wait_stream(self._side)       # join
         if exchange:
+            # the all-reduce (sum) runs eagerly between the two graphs; the 1/world goes into the Adam pass
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, pool=pool):
-                self.optimizer.step()
+                self.flat_adam.step(flat, 1.0 / self._world())
 
     def step(self, blocks_cf, target, next_blocks_cf=None):
         """blocks_cf [B,C,N] (channel-first like the reference loop, localfunctions.py:209),
@@ -249,8 +321,6 @@ class SemSegTrainer:
             self._static_next_x.copy_(blocks_cf if next_blocks_cf is None else next_blocks_cf)
         self._g_fwd_bwd.replay()
         if self._g_opt is not None:
-            world = self._world()
             dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)
-            self.grads.buffer.div_(world)
             self._g_opt.replay()
         return self._static_loss

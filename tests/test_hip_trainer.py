@@ -84,11 +84,37 @@ def test_prepare_captures_without_touching_the_model(monkeypatch):
     assert tr._g_fwd_bwd is not None
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k]), k
-    for st in tr.optimizer.state.values():
-        for v in st.values():
-            if torch.is_tensor(v):
-                assert float(v.abs().max()) == 0.0
+    for v in (tr.flat_adam.exp_avg, tr.flat_adam.exp_avg_sq, tr.flat_adam.state):
+        assert float(v.abs().max()) == 0.0
     got = np.array([float(tr.step(xs[i % 2], ys[i % 2], xs[(i + 1) % 2])) for i in range(steps)])
     assert abs(got[0] - ref[0]) <= 1e-4
     np.testing.assert_allclose(got, ref, rtol=2e-2)
     assert int(model.sa1.mlp_bns[0].num_batches_tracked) == steps
+
+
+def test_flat_adam_matches_torch_adam():
+    """pn2_adam_step (one pass over the flat parameter buffer) against torch.optim.Adam with the reference's
+    settings (sem_seg_training.py:576-582): three steps, L2 weight decay, bias correction, a learning-rate change
+    and a gradient scale."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd.train import FlatAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 67, 1), (64,), (13, 128, 1), (5,), (128, 128, 1)]
+    ref_p = [torch.nn.Parameter(torch.randn(sh, generator=g).double()) for sh in shapes]
+    our_p = [torch.nn.Parameter(p.detach().float().cuda()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    ours = FlatAdam(our_p, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    for step in range(3):
+        grads = [torch.randn(sh, generator=g) * (10.0 ** (step - 1)) for sh in shapes]
+        if step == 2:
+            for grp in ref.param_groups:
+                grp["lr"] = 7e-4
+            ours.set_lr(7e-4)
+        for p, gr in zip(ref_p, grads):
+            p.grad = gr.double() * 0.5
+        ref.step()
+        flat = torch.cat([gr.reshape(-1) for gr in grads]).cuda()
+        ours.step(flat, grad_scale=0.5)
+        for a, b in zip(our_p, ref_p):
+            torch.testing.assert_close(a.detach().cpu().double(), b.detach(), rtol=2e-6, atol=2e-7)
+    assert float(ours.state[0]) == 3.0
