@@ -695,6 +695,32 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
     }
 }
 
+// Fixed-order partial sums with all loads issued before the first add: thread slice py takes partials py,
+// py+32, ... (even ones into s0, odd ones into s1).  NJ = compile-time bound on the number per thread.
+template <int NJ>
+__device__ __forceinline__ void strided_sum(const float *__restrict__ base, size_t stride, int py, int P, float &s0, float &s1)
+{
+    float v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = base[(size_t)min(py + 32 * j, P - 1) * stride];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (py + 32 * j < P) { if (j & 1) s1 += v[j]; else s0 += v[j]; }
+}
+__device__ __forceinline__ void strided_sum_any(const float *__restrict__ base, size_t stride, int py, int P, float &s0, float &s1)
+{
+    if (P <= 32) strided_sum<1>(base, stride, py, P, s0, s1);
+    else if (P <= 64) strided_sum<2>(base, stride, py, P, s0, s1);
+    else if (P <= 128) strided_sum<4>(base, stride, py, P, s0, s1);
+    else if (P <= 256) strided_sum<8>(base, stride, py, P, s0, s1);
+    else if (P <= 512) strided_sum<16>(base, stride, py, P, s0, s1);
+    else {
+        int i = py;
+        for (; i + 32 < P; i += 64) { s0 += base[(size_t)i * stride]; s1 += base[(size_t)(i + 32) * stride]; }
+        if (i < P) s0 += base[(size_t)i * stride];
+    }
+}
+
 // partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
 // :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
 // estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
@@ -712,18 +738,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;            // <= 16 terms each: fp32 is exact enough here
-        int i = py;
-        for (; i + 32 < P; i += 64) {
-            s0 += partial[((size_t)i * 2 + 0) * C + c];
-            q0 += partial[((size_t)i * 2 + 1) * C + c];
-            s1 += partial[((size_t)(i + 32) * 2 + 0) * C + c];
-            q1 += partial[((size_t)(i + 32) * 2 + 1) * C + c];
-        }
-        if (i < P) {
-            s0 += partial[((size_t)i * 2 + 0) * C + c];
-            q0 += partial[((size_t)i * 2 + 1) * C + c];
-        }
+        // a thread's partials are all loaded before the first add: the loads are independent, a load-add loop
+        // would pay one memory round trip per iteration (this kernel runs 22 times per step)
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;            // <= 8 terms each: fp32 is exact enough here
+        strided_sum_any(partial + c, (size_t)2 * C, py, P, s0, s1);
+        strided_sum_any(partial + C + c, (size_t)2 * C, py, P, q0, q1);
         s = (double)s0 + (double)s1;
         q = (double)q0 + (double)q1;
     }
@@ -1185,12 +1204,7 @@ __device__ __forceinline__ void dw_reduce_block(int block, const float *__restri
     float s = 0.f;
     if (e < N * Kout) {
         float s0 = 0.f, s1 = 0.f;
-        int i = py;
-        for (; i + 32 < P; i += 64) {
-            s0 += partial[(size_t)i * stride + e];
-            s1 += partial[(size_t)(i + 32) * stride + e];
-        }
-        if (i < P) s0 += partial[(size_t)i * stride + e];
+        strided_sum_any(partial + e, stride, py, P, s0, s1);
         s = s0 + s1;
     }
     sS[py][el] = s;
@@ -1258,17 +1272,8 @@ __device__ __forceinline__ void bn_bwd_finalize_block(int block, const float *__
     double s = 0.0, q = 0.0;
     if (c < C) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-        int i = py;
-        for (; i + 32 < P; i += 64) {
-            s0 += partial[((size_t)i * 2 + 0) * C + c];
-            q0 += partial[((size_t)i * 2 + 1) * C + c];
-            s1 += partial[((size_t)(i + 32) * 2 + 0) * C + c];
-            q1 += partial[((size_t)(i + 32) * 2 + 1) * C + c];
-        }
-        if (i < P) {
-            s0 += partial[((size_t)i * 2 + 0) * C + c];
-            q0 += partial[((size_t)i * 2 + 1) * C + c];
-        }
+        strided_sum_any(partial + c, (size_t)2 * C, py, P, s0, s1);
+        strided_sum_any(partial + C + c, (size_t)2 * C, py, P, q0, q1);
         s = (double)s0 + (double)s1;
         q = (double)q0 + (double)q1;
     }
