@@ -167,26 +167,6 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     if (tid < C) slab[(size_t)tid * (K + 1) + K] = dba;
 }
 
-// dw[j][k] / db[j] = sum over slabs, in slab order (one thread per element, double accumulation).
-__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float *__restrict__ partial, int P, int C, int K,
-                                                            float *__restrict__ dw, float *__restrict__ db)
-{
-    __shared__ double sS[8][33];
-    const int el = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;
-    const int n = C * (K + 1);
-    double s = 0.0;
-    if (e < n)
-        for (int i = py; i < P; i += 8) s += (double)partial[(size_t)i * n + e];
-    sS[py][el] = s;
-    __syncthreads();
-    if (py != 0 || e >= n) return;
-    for (int i = 1; i < 8; ++i) s += sS[i][el];
-    const int j = e / (K + 1), k = e - j * (K + 1);
-    if (k < K) dw[(size_t)j * K + k] = (float)s;
-    else if (db) db[j] = (float)s;
-}
-
 // ---- weighted negative log-likelihood ---------------------------------------------------------------------
 // loss = sum_i -w[t_i] * logp[i][t_i] / sum_i w[t_i]   (rows with t_i == ignore_index are skipped,
 // F.nll_loss reduction='mean').  Partials per workgroup in double, combined in order.
@@ -279,9 +259,9 @@ PN2_EXPORT int pn2_head_logits_backward(const float *glogp, const float *logp, c
     const int P = pn2_head_logits_partials(M);
     hipLaunchKernelGGL(head_logits_backward_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
                        partial, M, K, C);
-    const int n = C * (K + 1);
-    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, P, C, K, dw, db);
-    return PN2_LAUNCH_RC();
+    int rc = PN2_LAUNCH_RC();
+    if (rc != PN2_OK) return rc;
+    return pn2::launch_dw_reduce(partial, P, C, K, dw, db, s);       // same slab layout as the MLP's dW partials
 }
 
 PN2_EXPORT int pn2_nll_loss_partials(long long M)
