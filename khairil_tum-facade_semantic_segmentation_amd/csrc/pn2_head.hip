@@ -14,6 +14,29 @@ constexpr int HD_KMAX = 128;       // feature width the kernels are built for
 constexpr int HD_CMAX = 32;        // classes
 constexpr int HD_LDY = HD_KMAX + 4;
 
+// 64 rows x K floats -> LDS tile: the (up to) 8 float4 of a thread are all loaded before the first LDS store,
+// unconditionally (clamped row, masked value): a load-store loop would wait for every load in turn.
+__device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy, int row0, int M, int k4n, float *__restrict__ sY, int tid)
+{
+    constexpr int NI = HD_ROWS * (HD_KMAX / 4) / HD_THREADS;          // 8
+    const int total = HD_ROWS * k4n;
+    float4 v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = min(tid + i * HD_THREADS, total - 1);
+        const int r = e / k4n, q = e - r * k4n;
+        v[i] = *reinterpret_cast<const float4 *>(&y[(size_t)min(row0 + r, M - 1) * ldy + 4 * q]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * HD_THREADS;
+        if (e < total) {
+            const int r = e / k4n, q = e - r * k4n;
+            *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = row0 + r < M ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
 // ---- forward -----------------------------------------------------------------------------------------
 // tile -> LDS, thread (row = t & 63, jq = t >> 6) accumulates classes jq, jq+4, ... over k in the
 // order k = 0..K-1 (one fma chain per class), then one thread per row does the log-softmax.
@@ -33,12 +56,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
         const int j = e / k4n, q = e - j * k4n;
         *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
     }
-    for (int e = tid; e < HD_ROWS * k4n; e += HD_THREADS) {
-        const int r = e / k4n, q = e - r * k4n;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < M) v = *reinterpret_cast<const float4 *>(&y[(size_t)(row0 + r) * ldy + 4 * q]);
-        *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = v;
-    }
+    stage_rows(y, ldy, row0, M, k4n, sY, tid);
     __syncthreads();
     const int r = tid & 63, jq = tid >> 6;
     float acc[CQ];
@@ -107,12 +125,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * HD_ROWS;
         __syncthreads();                                      // previous tile's readers are done (also covers sW)
-        for (int e = tid; e < HD_ROWS * k4n; e += HD_THREADS) {
-            const int r = e / k4n, q = e - r * k4n;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < M) v = *reinterpret_cast<const float4 *>(&y[(size_t)(row0 + r) * ldy + 4 * q]);
-            *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = v;
-        }
+        stage_rows(y, ldy, row0, M, k4n, sY, tid);
         if (tid < HD_ROWS) {
             const int row = row0 + tid;
             float gs = 0.f;

@@ -173,15 +173,25 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     const float *aRow = &sD[(rb * 32 + l31) * LDD + half * (NP / 2)];
                     const float *bCol = &sW[(half * (NP / 2)) * KP + cb * 32 + l31];
+                    // operands of group q+1 are read before the four MFMAs of group q are issued (the compiler
+                    // otherwise places every LDS read right in front of its consumer: read -> wait -> 2 MFMAs)
+                    float4 a4 = *reinterpret_cast<const float4 *>(aRow);
+                    float b0 = bCol[0], b1 = bCol[KP], b2 = bCol[2 * KP], b3 = bCol[3 * KP];
 #pragma unroll
                     for (int q = 0; q < NP / 8; ++q) {
-                        const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
-                        const float b0 = bCol[(4 * q + 0) * KP], b1 = bCol[(4 * q + 1) * KP];
-                        const float b2 = bCol[(4 * q + 2) * KP], b3 = bCol[(4 * q + 3) * KP];
+                        float4 a4n = a4;
+                        float b0n = b0, b1n = b1, b2n = b2, b3n = b3;
+                        if (q + 1 < NP / 8) {
+                            a4n = *reinterpret_cast<const float4 *>(aRow + 4 * (q + 1));
+                            b0n = bCol[(4 * q + 4) * KP]; b1n = bCol[(4 * q + 5) * KP];
+                            b2n = bCol[(4 * q + 6) * KP]; b3n = bCol[(4 * q + 7) * KP];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);         // keep the reads above the MFMAs
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+                        a4 = a4n; b0 = b0n; b1 = b1n; b2 = b2n; b3 = b3n;
                     }
                     const int col = cb * 32 + l31;
                     float cs = 0.f, cq = 0.f;
@@ -210,12 +220,26 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
                 const int nb = b / KBLK, kb = b - nb * KBLK;
                 const float *dBase = &sD[(32 * half) * LDD + nb * 32 + l31];
                 const float *xBase = &sZ[(32 * half) * LDZ + kb * 32 + l31];
-#pragma unroll 8
-                for (int t = 0; t < 32; ++t) {
-                    const float a = dBase[t * LDD];
-                    float x = xBase[t * LDZ];
-                    if (masked) x = fmaxf(wsc[i] * x + wsh[i], 0.f);
-                    accW[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x, accW[i], 0, 0, 0);
+                // same read-ahead: the operands of steps t+4..t+7 are in flight while steps t..t+3 multiply
+                float a[4], x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = dBase[u * LDD]; x[u] = xBase[u * LDZ]; }
+#pragma unroll
+                for (int t = 0; t < 32; t += 4) {
+                    float an[4], xn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        an[u] = a[u]; xn[u] = x[u];
+                        if (t + 4 < 32) { an[u] = dBase[(t + 4 + u) * LDD]; xn[u] = xBase[(t + 4 + u) * LDZ]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);             // keep the reads above the MFMAs
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xv = masked ? fmaxf(wsc[i] * x[u] + wsh[i], 0.f) : x[u];
+                        accW[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], xv, accW[i], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = an[u]; x[u] = xn[u]; }
                 }
             }
         }
