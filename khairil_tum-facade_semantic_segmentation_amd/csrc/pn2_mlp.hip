@@ -631,20 +631,25 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
         const float *sA = sAbuf + (step & 1) * SA_ELEMS;
         const float *sB = sBbuf + (step & 1) * SB_ELEMS;
         const float *aRow = &sA[(rw * 32 + l31) * MLP_LD + 16 * half];
+        // Operand read-ahead (left alone, the compiler puts every LDS read right in front of its consumer:
+        // read -> wait -> MFMAs).  Not in mlp_gemm_pipe_kernel: its 8-wave form has no registers to spare.
+        auto load_b = [&](int q) -> float4 {
+            if (!WT) return *reinterpret_cast<const float4 *>(&sB[(cw * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
+            const float *bp = &sB[(16 * half + 4 * q) * LDBT + cw * 32 + l31];
+            return make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
+        };
+        float4 a4 = *reinterpret_cast<const float4 *>(aRow);
+        float4 b4 = load_b(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(aRow + 4 * q);
-            float4 b4;
-            if (!WT) {
-                b4 = *reinterpret_cast<const float4 *>(&sB[(cw * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
-            } else {
-                const float *bp = &sB[(16 * half + 4 * q) * LDBT + cw * 32 + l31];
-                b4 = make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
-            }
+            float4 an = a4, bn = b4;
+            if (q + 1 < 4) { an = *reinterpret_cast<const float4 *>(aRow + 4 * (q + 1)); bn = load_b(q + 1); }
+            __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            a4 = an; b4 = bn;
         }
         const int t = step / nk, kc = step - t * nk;
         if (kc == nk - 1) {
@@ -992,14 +997,21 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
         // MFMA: i = n (dz column), j = k (act column), reduction over this wave's 32 rows
         const float *dBase = &sD[(wave * 32 + 16 * half) * DW_LD];
         const float *xBase = &sX[(wave * 32 + 16 * half) * DW_LD];
+        // operand read-ahead (one step) as in mlp_gemm_rows32_kernel
+        float a0 = dBase[l31], a1v = dBase[32 + l31], b0 = xBase[l31], b1 = xBase[32 + l31];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float a0 = dBase[t * DW_LD + l31], a1v = dBase[t * DW_LD + 32 + l31];
-            const float b0 = xBase[t * DW_LD + l31], b1 = xBase[t * DW_LD + 32 + l31];
+            float a0n = a0, a1n = a1v, b0n = b0, b1n = b1;
+            if (t + 1 < 16) {
+                a0n = dBase[(t + 1) * DW_LD + l31]; a1n = dBase[(t + 1) * DW_LD + 32 + l31];
+                b0n = xBase[(t + 1) * DW_LD + l31]; b1n = xBase[(t + 1) * DW_LD + 32 + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc[1][1], 0, 0, 0);
+            a0 = a0n; a1v = a1n; b0 = b0n; b1 = b1n;
         }
         __syncthreads();
     }
