@@ -118,3 +118,55 @@ def test_flat_adam_matches_torch_adam():
         for a, b in zip(our_p, ref_p):
             torch.testing.assert_close(a.detach().cpu().double(), b.detach(), rtol=2e-6, atol=2e-7)
     assert float(ours.state[0]) == 3.0
+
+
+def _dp_worker(rank, world, port, out):
+    """One data-parallel rank on the (shared) GPU: gloo process group, captured graphs, own batch."""
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khairil_tum_facade_semantic_segmentation_amd import synth
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+    from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
+    from oracle import pn2_oracle as orc
+    real_randint = torch.randint
+    torch.randint = lambda low, high, size, **kw: real_randint(0, 1, size, **kw)      # same FPS starts everywhere
+    dev = torch.device("cuda:0")
+    d = synth.draw_case(100 + rank, 2, 1024, 9, "cube", 18)                          # every rank its own blocks
+    x = torch.from_numpy(np.ascontiguousarray(d[0].transpose(0, 2, 1))).to(dev)
+    y = torch.from_numpy(d[1]).to(dev)
+    model = M.get_model(18, 3)
+    filled = synth.fill_state_dict(orc.state_shapes(18, 3))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model = model.to(dev)
+    model.drop1.p = 0.0
+    tr = SemSegTrainer(model, class_weight=torch.ones(18, device=dev), graphs=True, prefetch_geometry=True, graph_warmup=1)
+    tr.prepare(x, y)                      # capture before the first collective
+    tr.broadcast_parameters()
+    losses = [float(tr.step(x, y)) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert tr._g_opt is not None          # the two-graph exchange path was taken
+    flat = tr.flat_adam.flat.detach().cpu().numpy()
+    np.save(os.path.join(out, "params_rank%d.npy" % rank), flat)
+    np.save(os.path.join(out, "loss_rank%d.npy" % rank), np.array(losses))
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_on_one_gpu(tmp_path):
+    """world_size 2 (gloo, both ranks on this GPU): graph-captured forward/backward, all-reduce of the packed
+    gradients between the graphs, flat Adam with the 1/world folded in.  Replicas must stay bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "params_rank0.npy"), np.load(tmp_path / "params_rank1.npy")
+    assert np.array_equal(p0, p1)
+    l0, l1 = np.load(tmp_path / "loss_rank0.npy"), np.load(tmp_path / "loss_rank1.npy")
+    assert np.isfinite(l0).all() and np.isfinite(l1).all() and not np.array_equal(l0, l1)
