@@ -90,6 +90,49 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float *__restri
     grouped[(size_t)bs * row_elems + f] = v;
 }
 
+// The same with one float4 of the output row per thread (pitch ldg % 4 == 0, 16-byte aligned output): quad 0 is
+// [xyz - centroid, feat 0], quad q > 0 is feats 4q-3 .. 4q (a 16-byte load that is only 4-byte aligned), columns
+// past 3+D are the zero pad.  Four times fewer threads, 16-byte stores.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+
+__global__ __launch_bounds__(256) void group_points_vec4_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                const float *__restrict__ points, const int64_t *__restrict__ idx,
+                                                                int N, int S, int K, int D, int ldg, unsigned q_magic,
+                                                                float *__restrict__ grouped, int32_t *err_count)
+{
+    const int Cg = 3 + D, qpr = ldg >> 2;              // quads per row
+    const int quads = K * qpr;
+    const int f = blockIdx.y * 256 + threadIdx.x;
+    if (f >= quads) return;
+    const unsigned bs = blockIdx.x;                    // b*S + s
+    const unsigned b = bs / (unsigned)S;
+    const int k = qpr == 1 ? f : (int)__umulhi((unsigned)f, q_magic);
+    const int q = f - k * qpr;
+    const int64_t j = idx[(size_t)bs * K + k];
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (j >= 0 && j < N) {
+        const float *row = points ? points + ((size_t)b * N + j) * D : nullptr;
+        if (q == 0) {
+            const f32x3u p3 = *reinterpret_cast<const f32x3u *>(xyz + ((size_t)b * N + j) * 3);
+            const f32x3u c3 = *reinterpret_cast<const f32x3u *>(new_xyz + (size_t)bs * 3);
+            v = make_float4(p3.x - c3.x, p3.y - c3.y, p3.z - c3.z, D > 0 ? row[0] : 0.0f);      // :128, :131
+        } else {
+            const int c0 = 4 * q - 3;                  // first feature of this quad
+            if (c0 + 4 <= D) {
+                const f32x4u t = *reinterpret_cast<const f32x4u *>(row + c0);
+                v = make_float4(t.x, t.y, t.z, t.w);
+            } else {                                   // tail quad: some columns are pad
+                if (c0 < D) v.x = row[c0];
+                if (c0 + 1 < D) v.y = row[c0 + 1];
+                if (c0 + 2 < D) v.z = row[c0 + 2];
+            }
+        }
+    } else if (q == 0 && err_count) atomicAdd(err_count, 1);
+    (void)Cg;
+    reinterpret_cast<float4 *>(grouped + (size_t)bs * K * ldg)[f] = v;
+}
+
 __global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src,
                                                               const float *__restrict__ dst, long long total,
                                                               int N, int M, float *__restrict__ out)
@@ -191,6 +234,18 @@ PN2_EXPORT int pn2_group_points(const float *xyz, const float *new_xyz, const fl
     const long long rows = (long long)B * S;
     const long long ny = (row_elems + 255) / 256;
     if (rows > 0x7fffffffLL || ny > 65535 || row_elems + 256 >= (1LL << 32) / Cg) return PN2_ERR_UNSUPPORTED;
+    if ((ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(grouped) & 15) == 0 && pn2::tune_get("group_vec4", 1)) {
+        const int qpr = ldg >> 2;
+        const long long quads = (long long)K * qpr;
+        const long long nyq = (quads + 255) / 256;
+        if (nyq <= 65535) {
+            const unsigned qmagic = qpr > 1 ? (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u : 0u;
+            hipLaunchKernelGGL(group_points_vec4_kernel, dim3((unsigned)rows, (unsigned)nyq), dim3(256), 0,
+                               static_cast<hipStream_t>(stream_), xyz, new_xyz, points, idx, N, S, K, D, ldg, qmagic, grouped,
+                               err_count);
+            return PN2_LAUNCH_RC();
+        }
+    }
     const unsigned magic = (unsigned)((1ULL << 32) / (unsigned)Cg) + 1u;     // umulhi(f, magic) == f / Cg
     hipLaunchKernelGGL(group_points_kernel, dim3((unsigned)rows, (unsigned)ny), dim3(256), 0,
                        static_cast<hipStream_t>(stream_), xyz, new_xyz, points, idx, N, S, K, D, ldg, magic, grouped,
