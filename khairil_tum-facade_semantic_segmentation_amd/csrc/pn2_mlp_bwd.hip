@@ -292,6 +292,245 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-role form for the narrowest layers (K <= 32, N <= 64: the three layers of SA1, M = 524 288 rows).
+// There a tile's MFMA work fits four waves (2 dX blocks + NBLK dW blocks) and the kernel above runs at
+// memory time + MFMA time, because staging and multiplying alternate inside every workgroup.  Here the
+// roles are split: waves 2..5 only STAGE (global loads -> dz / input tile of step t+1 into the other LDS
+// buffer, prefetching t+2), waves 0,1,6,7 only MULTIPLY tile t; one barrier per tile.
+// The roles are separate code paths, so each gets its own register allocation (78-104 VGPRs, 2-3 workgroups per CU).
+template <int NBLK, bool POOLED>
+__global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
+{
+    constexpr int NP = 32 * NBLK, KP = 32;
+    constexpr int LDD = NP + 4, LDZ = KP + 4;
+    constexpr int ST = 256;                           // staging threads (waves 2..5)
+    constexpr int DROWS = ST / (NP / 4), XROWS = ST / (KP / 4);
+    constexpr int DPASS = FB_ROWS / DROWS, XPASS = FB_ROWS / XROWS;
+    constexpr int TILE = FB_ROWS * LDD + FB_ROWS * LDZ;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sW = smem + 2 * TILE;                      // [NP][KP]
+    float *red = smem;                                // after the loop: [DROWS][NP] bias-gradient partials ...
+    float *red2 = smem + DROWS * NP;                  // ... and [2][2][KP] statistics of the two dX waves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (p.M + FB_ROWS - 1) / FB_ROWS;
+    const bool masked = p.ascale != nullptr;
+    const int G = gridDim.x;
+    const int t0 = blockIdx.x;                        // < ntiles (the grid never exceeds the tile count)
+    const int Kout = p.K + 1;
+    float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout;
+
+    for (int e = tid; e < NP * (KP / 4); e += FB_THREADS) {
+        const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.N && k4 < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k4);
+        *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = v;
+    }
+
+    // The two roles are two separate code paths (wave-uniform branch), each with its own registers; both
+    // execute exactly the same sequence of barriers: A (weights in LDS), B (first tile staged), one per tile.
+    if (wave >= 2 && wave < 6) {
+        // ================================ stagers =================================================
+        const int stid = tid - 128;
+        const int dc4 = (stid % (NP / 4)) * 4, dr = stid / (NP / 4);
+        const int xc4 = (stid % (KP / 4)) * 4, xr = stid / (KP / 4);
+        const bool n_ok = dc4 < p.N, k_ok = xc4 < p.K;
+        const int dcc = n_ok ? dc4 : 0, xcc = k_ok ? xc4 : 0;
+        float4 sc, sh, mu, is, a1, a2;
+        sc = sh = mu = is = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dbs = sc;
+        if (n_ok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + dc4);
+            sh = *reinterpret_cast<const float4 *>(p.shift + dc4);
+            mu = *reinterpret_cast<const float4 *>(p.mean + dc4);
+            is = *reinterpret_cast<const float4 *>(p.invstd + dc4);
+            a1 = *reinterpret_cast<const float4 *>(p.c1 + dc4);
+            a2 = *reinterpret_cast<const float4 *>(p.c2 + dc4);
+        }
+        float4 gv[DPASS], zv[DPASS], xv[XPASS];
+        uchar4 av[DPASS];
+        auto issue = [&](int tile) {
+            const int row0 = tile * FB_ROWS;
+#pragma unroll
+            for (int i = 0; i < DPASS; ++i) {
+                const int row = min(row0 + dr + DROWS * i, p.M - 1);
+                if (POOLED) {
+                    const int cent = row / p.pool_k;
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + dcc);
+                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + dcc);
+                } else {
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + dcc);
+                }
+                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + dcc);
+            }
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const int row = min(row0 + xr + XROWS * i, p.M - 1);
+                xv[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.ldx + xcc);
+            }
+        };
+        auto commit = [&](int tile, int buf) {
+            float *sD = smem + buf * TILE, *sZ = sD + FB_ROWS * LDD;
+            const int row0 = tile * FB_ROWS;
+#pragma unroll
+            for (int i = 0; i < DPASS; ++i) {
+                const int r = dr + DROWS * i;
+                const int row = row0 + r;
+                float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < p.M && n_ok) {
+                    float4 g = gv[i];
+                    if (POOLED) {
+                        const int kk = row % p.pool_k;
+                        g.x = av[i].x == kk ? g.x : 0.f;
+                        g.y = av[i].y == kk ? g.y : 0.f;
+                        g.z = av[i].z == kk ? g.z : 0.f;
+                        g.w = av[i].w == kk ? g.w : 0.f;
+                    }
+                    const float4 z = zv[i];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                    PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                    dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
+                }
+                *reinterpret_cast<float4 *>(&sD[r * LDD + dc4]) = dv;
+            }
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const bool ok = k_ok && row0 + xr + XROWS * i < p.M;
+                *reinterpret_cast<float4 *>(&sZ[(xr + XROWS * i) * LDZ + xc4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        issue(t0);
+        __syncthreads();                              // A
+        commit(t0, 0);
+        if (t0 + G < ntiles) issue(t0 + G);
+        __syncthreads();                              // B
+        int buf = 0;
+        for (int tile = t0; tile < ntiles; tile += G, buf ^= 1) {
+            if (tile + G < ntiles) {
+                commit(tile + G, buf ^ 1);
+                if (tile + 2 * G < ntiles) issue(tile + 2 * G);
+            }
+            __syncthreads();                          // tile
+        }
+        *reinterpret_cast<float4 *>(&red[dr * NP + dc4]) = dbs;      // tile buffers are free now
+    } else {
+        // ================================ multipliers ================================================
+        // waves 0,1: the dX blocks (rows 32*wave..); waves 7 (and 6): the dW blocks (columns 32*(7-wave)..)
+        const bool dx_wave = wave < 2, dw_wave = wave >= 8 - NBLK;
+        const int col = l31;
+        float xsc = 0.f, xsh = 0.f, xmu = 0.f, xis = 0.f, csum = 0.f, csq = 0.f;
+        if (masked && col < p.K) { xsc = p.ascale[col]; xsh = p.ashift[col]; xmu = p.amean[col]; xis = p.ainvstd[col]; }
+        f32x16 accW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[r] = 0.f;
+        asm volatile("" ::"v"(xsc), "v"(xsh), "v"(xmu), "v"(xis));   // arrived before the loop (in-order vmcnt)
+        __syncthreads();                              // A
+        __syncthreads();                              // B
+        int buf = 0;
+        for (int tile = t0; tile < ntiles; tile += G, buf ^= 1) {
+            const float *sD = smem + buf * TILE, *sZ = sD + FB_ROWS * LDD;
+            const int row0 = tile * FB_ROWS;
+            if (dx_wave && p.gp) {
+                const int rb = wave;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float *aRow = &sD[(rb * 32 + l31) * LDD + half * (NP / 2)];
+                const float *bCol = &sW[(half * (NP / 2)) * KP + l31];
+                float4 a4 = *reinterpret_cast<const float4 *>(aRow);
+                float b0 = bCol[0], b1 = bCol[KP], b2 = bCol[2 * KP], b3 = bCol[3 * KP];
+#pragma unroll
+                for (int q = 0; q < NP / 8; ++q) {
+                    float4 a4n = a4;
+                    float b0n = b0, b1n = b1, b2n = b2, b3n = b3;
+                    if (q + 1 < NP / 8) {
+                        a4n = *reinterpret_cast<const float4 *>(aRow + 4 * (q + 1));
+                        b0n = bCol[(4 * q + 4) * KP]; b1n = bCol[(4 * q + 5) * KP];
+                        b2n = bCol[(4 * q + 6) * KP]; b3n = bCol[(4 * q + 7) * KP];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+                    a4 = a4n; b0 = b0n; b1 = b1n; b2 = b2n; b3 = b3n;
+                }
+                float cs = 0.f, cq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[r];
+                    if (masked) {
+                        const float zp = sZ[rl * LDZ + col];
+                        v = (xsc * zp + xsh) > 0.f ? v : 0.f;
+                        cs += v;
+                        cq += v * ((zp - xmu) * xis);
+                    }
+                    if (row0 + rl < p.M && col < p.K) p.gp[(size_t)(row0 + rl) * p.ldgp + col] = v;
+                }
+                csum += cs;
+                csq += cq;
+            }
+            if (dw_wave) {
+                const int nb = 7 - wave;
+                const float *dBase = &sD[(32 * half) * LDD + nb * 32 + l31];
+                const float *xBase = &sZ[(32 * half) * LDZ + l31];
+                float a[4], x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = dBase[u * LDD]; x[u] = xBase[u * LDZ]; }
+#pragma unroll
+                for (int t = 0; t < 32; t += 4) {
+                    float an[4], xn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        an[u] = a[u]; xn[u] = x[u];
+                        if (t + 4 < 32) { an[u] = dBase[(t + 4 + u) * LDD]; xn[u] = xBase[(t + 4 + u) * LDZ]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xv2 = masked ? fmaxf(xsc * x[u] + xsh, 0.f) : x[u];
+                        accW = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], xv2, accW, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = an[u]; x[u] = xn[u]; }
+                }
+            }
+            __syncthreads();                          // tile
+        }
+        if (dw_wave) {
+            const int nb = 7 - wave;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < p.N && col < p.K) slab[(size_t)n * Kout + col] = accW[r];
+            }
+        }
+        if (dx_wave) {
+            const float s = csum + __shfl_xor(csum, 32), q = csq + __shfl_xor(csq, 32);
+            if (half == 0) { red2[(wave * 2 + 0) * KP + l31] = s; red2[(wave * 2 + 1) * KP + l31] = q; }
+        }
+    }
+    __syncthreads();
+    if (tid < p.N) {
+        float t = 0.f;
+        for (int i = 0; i < DROWS; ++i) t += red[i * NP + tid];
+        slab[(size_t)tid * Kout + p.K] = t;
+    }
+    if (p.stat_partial) {
+        for (int e = tid; e < 2 * p.K; e += FB_THREADS) {
+            const int which = e / p.K, c = e - which * p.K;
+            p.stat_partial[((size_t)blockIdx.x * 2 + which) * p.K + c] = red2[(0 * 2 + which) * KP + c] + red2[(1 * 2 + which) * KP + c];
+        }
+    }
+}
+
+template <int NBLK>
+constexpr int fs_lds_bytes() { return (2 * (FB_ROWS * (32 * NBLK + 4) + FB_ROWS * 36) + 32 * NBLK * 32) * 4; }
+
 template <int NBLK, int KBLK>
 constexpr int fb_lds_bytes() { return (FB_ROWS * (32 * NBLK + 4) + FB_ROWS * (32 * KBLK + 4) + 32 * NBLK * 32 * KBLK) * 4; }
 
@@ -325,6 +564,31 @@ int fb_resident_of()
     return cached;
 }
 
+
+template <int NBLK, bool POOLED>
+int fs_resident_of()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    constexpr int lds = fs_lds_bytes<NBLK>();
+    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_split_kernel<NBLK, POOLED>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_split_kernel<NBLK, POOLED>, FB_THREADS, lds) != hipSuccess) return 0;
+    cached = n < 1 ? 0 : (n > 4 ? 4 : n);
+    return cached;
+}
+
+// split-role kernel: K <= 32 and N <= 64 (PN2_TUNE_FB_SPLIT=0 switches it off)
+bool fs_applies(int nblk, int kblk) { return kblk == 1 && nblk <= 2 && pn2::tune_get("fb_split", 1) != 0; }
+
+int fs_resident_rt(int nblk)
+{
+    const int a = nblk == 1 ? fs_resident_of<1, false>() : fs_resident_of<2, false>();
+    const int b = nblk == 1 ? fs_resident_of<1, true>() : fs_resident_of<2, true>();
+    return a < b ? a : b;
+}
+
 int fb_resident_rt(int nblk, int kblk)
 {
 #define PN2_FB(NB, KB) if (nblk == NB && kblk == KB) return fb_resident<NB, KB>()
@@ -351,7 +615,8 @@ int fb_launch(const BwdArgs &a, int grid, hipStream_t stream)
 PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0 || N > 128 || K > 128 || (N & 3) || (K & 3)) return 0;
-    int per_cu = fb_resident_rt(fb_blocks(N), fb_blocks(K));
+    const int nblk_ = fb_blocks(N), kblk_ = fb_blocks(K);
+    int per_cu = fs_applies(nblk_, kblk_) ? fs_resident_rt(nblk_) : fb_resident_rt(nblk_, kblk_);
     if (per_cu < 1) return 0;
     int cus = 256;
     {
@@ -403,11 +668,19 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int nblk = fb_blocks(N), kblk = fb_blocks(K);
     int rc = PN2_ERR_UNSUPPORTED;
+    if (fs_applies(nblk, kblk)) {
+#define PN2_FS(NB, PO) hipLaunchKernelGGL((mlp_bwd_split_kernel<NB, PO>), dim3(P), dim3(FB_THREADS), (fs_lds_bytes<NB>()), stream, a)
+        if (nblk == 1) { if (argk) PN2_FS(1, true); else PN2_FS(1, false); }
+        else { if (argk) PN2_FS(2, true); else PN2_FS(2, false); }
+#undef PN2_FS
+        rc = PN2_LAUNCH_RC();
+    } else {
 #define PN2_FB(NB, KB) if (nblk == NB && kblk == KB) rc = fb_launch<NB, KB>(a, P, stream)
     PN2_FB(1, 1); PN2_FB(1, 2); PN2_FB(1, 4);
     PN2_FB(2, 1); PN2_FB(2, 2); PN2_FB(2, 4);
     PN2_FB(4, 1); PN2_FB(4, 2); PN2_FB(4, 4);
 #undef PN2_FB
+    }
     if (rc != PN2_OK) return rc;
     if (c1_below)                                    // BatchNorm-backward constants of the layer below, same launch
         return pn2::launch_bwd_post(dw_partial, P, N, K, dw, db, stat_partial, P, K, (double)M, dgamma_below, dbeta_below, c1_below,
