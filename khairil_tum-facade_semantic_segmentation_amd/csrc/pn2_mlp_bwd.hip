@@ -531,6 +531,301 @@ __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
 template <int NBLK>
 constexpr int fs_lds_bytes() { return (2 * (FB_ROWS * (32 * NBLK + 4) + FB_ROWS * 36) + 32 * NBLK * 32) * 4; }
 
+// ---------------------------------------------------------------------------------------------------------
+// General split-role form: NMW multiplier waves (all dX / dW blocks of a TR-row tile spread over them) and NSW
+// staging waves, double-buffered tiles, one barrier per tile.  Used for the 128 x 128 layers (TR = 32: the weight
+// tile plus two 32-row tile buffers fit the LDS; 8 + 4 waves): the multiplier waves issue MFMAs back to back
+// instead of alternating with the staging code.
+template <int NBLK, int KBLK, bool POOLED, int TR, int NMW, int NSW>
+__global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(BwdArgs p)
+{
+    constexpr int THREADS = 64 * (NMW + NSW), ST = 64 * NSW;
+    constexpr int NP = 32 * NBLK, KP = 32 * KBLK;
+    constexpr int LDD = NP + 4, LDZ = KP + 4;
+    constexpr int RB = TR / 32;
+    constexpr int NDX = RB * KBLK, NDW = NBLK * KBLK;
+    constexpr int DXPW = (NDX + NMW - 1) / NMW;
+    // dW blocks: the waves without a dX block (NUP of them) take DWHI each, the dX waves share the rest (DWLO each),
+    // so that the two multiplier waves of a SIMD carry about the same number of MFMAs per tile
+    constexpr int NUP = NMW > NDX ? NMW - NDX : 0;
+    constexpr int UNITS = NDW + NDX * (NP / TR);       // work in dW-block units (a dX block costs NP/TR of them)
+    constexpr int TARGET = (UNITS + NMW - 1) / NMW;
+    constexpr int DWHI = NUP ? (TARGET < NDW / NUP ? TARGET : NDW / NUP) : 0;
+    constexpr int DWLO = NUP ? (NDW - NUP * DWHI + NDX - 1) / (NDX ? NDX : 1) : (NDW + NMW - 1) / NMW;
+    constexpr int DWPW = DWHI > DWLO ? DWHI : DWLO;
+    constexpr int DROWS = ST / (NP / 4), XROWS = ST / (KP / 4);
+    constexpr int DPASS = TR / DROWS, XPASS = TR / XROWS;
+    static_assert(DPASS * DROWS == TR && XPASS * XROWS == TR, "staging rows must divide the tile");
+    constexpr int TILE = TR * LDD + TR * LDZ;
+    static_assert(ST * 4 + RB * 2 * KP <= 2 * TILE, "reduction scratch does not fit");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sW = smem + 2 * TILE;                      // [NP][KP]
+    float *red = smem;                                // after the loop: [DROWS][NP] bias-gradient partials ...
+    float *red2 = smem + ST * 4;                      // ... and [RB][2][KP] statistics of the dX blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (p.M + TR - 1) / TR;
+    const bool masked = p.ascale != nullptr;
+    const int G = gridDim.x;
+    const int t0 = blockIdx.x;                        // < ntiles (the grid never exceeds the tile count)
+    const int Kout = p.K + 1;
+    float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout;
+
+    for (int e = tid; e < NP * (KP / 4); e += THREADS) {
+        const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.N && k4 < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k4);
+        *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = v;
+    }
+
+    if (wave >= NMW) {
+        // ================================ stagers =================================================
+        const int stid = tid - 64 * NMW;
+        const int dc4 = (stid % (NP / 4)) * 4, dr = stid / (NP / 4);
+        const int xc4 = (stid % (KP / 4)) * 4, xr = stid / (KP / 4);
+        const bool n_ok = dc4 < p.N, k_ok = xc4 < p.K;
+        const int dcc = n_ok ? dc4 : 0, xcc = k_ok ? xc4 : 0;
+        float4 sc, sh, mu, is, a1, a2;
+        sc = sh = mu = is = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dbs = sc;
+        if (n_ok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + dc4);
+            sh = *reinterpret_cast<const float4 *>(p.shift + dc4);
+            mu = *reinterpret_cast<const float4 *>(p.mean + dc4);
+            is = *reinterpret_cast<const float4 *>(p.invstd + dc4);
+            a1 = *reinterpret_cast<const float4 *>(p.c1 + dc4);
+            a2 = *reinterpret_cast<const float4 *>(p.c2 + dc4);
+        }
+        float4 gv[DPASS], zv[DPASS], xv[XPASS];
+        uchar4 av[DPASS];
+        auto issue = [&](int tile) {
+            const int row0 = tile * TR;
+#pragma unroll
+            for (int i = 0; i < DPASS; ++i) {
+                const int row = min(row0 + dr + DROWS * i, p.M - 1);
+                if (POOLED) {
+                    const int cent = row / p.pool_k;
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + dcc);
+                    av[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + dcc);
+                } else {
+                    gv[i] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + dcc);
+                }
+                zv[i] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + dcc);
+            }
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const int row = min(row0 + xr + XROWS * i, p.M - 1);
+                xv[i] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.ldx + xcc);
+            }
+        };
+        auto commit = [&](int tile, int buf) {
+            float *sD = smem + buf * TILE, *sZ = sD + TR * LDD;
+            const int row0 = tile * TR;
+#pragma unroll
+            for (int i = 0; i < DPASS; ++i) {
+                const int r = dr + DROWS * i;
+                const int row = row0 + r;
+                float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < p.M && n_ok) {
+                    float4 g = gv[i];
+                    if (POOLED) {
+                        const int kk = row % p.pool_k;
+                        g.x = av[i].x == kk ? g.x : 0.f;
+                        g.y = av[i].y == kk ? g.y : 0.f;
+                        g.z = av[i].z == kk ? g.z : 0.f;
+                        g.w = av[i].w == kk ? g.w : 0.f;
+                    }
+                    const float4 z = zv[i];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                    PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                    dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
+                }
+                *reinterpret_cast<float4 *>(&sD[r * LDD + dc4]) = dv;
+            }
+#pragma unroll
+            for (int i = 0; i < XPASS; ++i) {
+                const bool ok = k_ok && row0 + xr + XROWS * i < p.M;
+                *reinterpret_cast<float4 *>(&sZ[(xr + XROWS * i) * LDZ + xc4]) = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        issue(t0);
+        __syncthreads();                              // A
+        commit(t0, 0);
+        if (t0 + G < ntiles) issue(t0 + G);
+        __syncthreads();                              // B
+        int buf = 0;
+        for (int tile = t0; tile < ntiles; tile += G, buf ^= 1) {
+            if (tile + G < ntiles) {
+                commit(tile + G, buf ^ 1);
+                if (tile + 2 * G < ntiles) issue(tile + 2 * G);
+            }
+            __syncthreads();                          // tile
+        }
+        *reinterpret_cast<float4 *>(&red[dr * NP + dc4]) = dbs;      // tile buffers are free now
+    } else {
+        // ================================ multipliers ================================================
+        // dX block b = rb*KBLK + cb on wave b % NMW (slot b / NMW); dW blocks: see DWHI / DWLO
+        auto dw_block = [&](int i) -> int {
+            if (NUP == 0) { const int b = (NMW - 1 - wave) + NMW * i; return b < NDW ? b : -1; }
+            if (wave >= NDX) return i < DWHI ? (wave - NDX) * DWHI + i : -1;
+            const int b = NUP * DWHI + wave * DWLO + i;
+            return (i < DWLO && b < NDW) ? b : -1;
+        };
+        float xsc[DXPW], xsh[DXPW], xmu[DXPW], xis[DXPW], csum[DXPW], csq[DXPW];
+#pragma unroll
+        for (int i = 0; i < DXPW; ++i) {
+            const int b = wave + NMW * i;
+            const int col = (b % KBLK) * 32 + l31;
+            xsc[i] = xsh[i] = xmu[i] = xis[i] = csum[i] = csq[i] = 0.f;
+            if (masked && b < NDX && col < p.K) {
+                xsc[i] = p.ascale[col]; xsh[i] = p.ashift[col]; xmu[i] = p.amean[col]; xis[i] = p.ainvstd[col];
+            }
+        }
+        float wsc[DWPW], wsh[DWPW];
+        f32x16 accW[DWPW];
+#pragma unroll
+        for (int i = 0; i < DWPW; ++i) {
+            const int b = dw_block(i);
+            const int col = ((b < 0 ? 0 : b) % KBLK) * 32 + l31;
+            wsc[i] = wsh[i] = 0.f;
+            if (masked && b >= 0 && col < p.K) { wsc[i] = p.ascale[col]; wsh[i] = p.ashift[col]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[i][r] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < DXPW; ++i) asm volatile("" ::"v"(xsc[i]), "v"(xsh[i]), "v"(xmu[i]), "v"(xis[i]));
+#pragma unroll
+        for (int i = 0; i < DWPW; ++i) asm volatile("" ::"v"(wsc[i]), "v"(wsh[i]));
+        __syncthreads();                              // A
+        __syncthreads();                              // B
+        int buf = 0;
+        for (int tile = t0; tile < ntiles; tile += G, buf ^= 1) {
+            const float *sD = smem + buf * TILE, *sZ = sD + TR * LDD;
+            const int row0 = tile * TR;
+            if (p.gp) {
+#pragma unroll
+                for (int i = 0; i < DXPW; ++i) {
+                    const int b = wave + NMW * i;
+                    if (b < NDX) {
+                        const int rb = b / KBLK, cb = b - rb * KBLK;
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        const float *aRow = &sD[(rb * 32 + l31) * LDD + half * (NP / 2)];
+                        const float *bCol = &sW[(half * (NP / 2)) * KP + cb * 32 + l31];
+                        float4 a4 = *reinterpret_cast<const float4 *>(aRow);
+                        float b0 = bCol[0], b1 = bCol[KP], b2 = bCol[2 * KP], b3 = bCol[3 * KP];
+#pragma unroll
+                        for (int q = 0; q < NP / 8; ++q) {
+                            float4 a4n = a4;
+                            float b0n = b0, b1n = b1, b2n = b2, b3n = b3;
+                            if (q + 1 < NP / 8) {
+                                a4n = *reinterpret_cast<const float4 *>(aRow + 4 * (q + 1));
+                                b0n = bCol[(4 * q + 4) * KP]; b1n = bCol[(4 * q + 5) * KP];
+                                b2n = bCol[(4 * q + 6) * KP]; b3n = bCol[(4 * q + 7) * KP];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+                            a4 = a4n; b0 = b0n; b1 = b1n; b2 = b2n; b3 = b3n;
+                        }
+                        const int col = cb * 32 + l31;
+                        float cs = 0.f, cq = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            float v = acc[r];
+                            if (masked) {
+                                const float zp = sZ[rl * LDZ + col];
+                                v = (xsc[i] * zp + xsh[i]) > 0.f ? v : 0.f;
+                                cs += v;
+                                cq += v * ((zp - xmu[i]) * xis[i]);
+                            }
+                            if (row0 + rl < p.M && col < p.K) p.gp[(size_t)(row0 + rl) * p.ldgp + col] = v;
+                        }
+                        csum[i] += cs;
+                        csq[i] += cq;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DWPW; ++i) {
+                const int b = dw_block(i);
+                if (b >= 0) {
+                    const int nb = b / KBLK, kb = b - nb * KBLK;
+                    constexpr int HR = TR / 2;                       // rows per lane half
+                    const float *dBase = &sD[(HR * half) * LDD + nb * 32 + l31];
+                    const float *xBase = &sZ[(HR * half) * LDZ + kb * 32 + l31];
+                    float a[4], x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = dBase[u * LDD]; x[u] = xBase[u * LDZ]; }
+#pragma unroll
+                    for (int t = 0; t < HR; t += 4) {
+                        float an[4], xn[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            an[u] = a[u]; xn[u] = x[u];
+                            if (t + 4 < HR) { an[u] = dBase[(t + 4 + u) * LDD]; xn[u] = xBase[(t + 4 + u) * LDZ]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float xv2 = masked ? fmaxf(wsc[i] * x[u] + wsh[i], 0.f) : x[u];
+                            accW[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], xv2, accW[i], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { a[u] = an[u]; x[u] = xn[u]; }
+                    }
+                }
+            }
+            __syncthreads();                          // tile
+        }
+#pragma unroll
+        for (int i = 0; i < DWPW; ++i) {
+            const int b = dw_block(i);
+            if (b >= 0) {
+                const int nb = b / KBLK, kb = b - nb * KBLK;
+                const int k = kb * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (n < p.N && k < p.K) slab[(size_t)n * Kout + k] = accW[i][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DXPW; ++i) {
+            const int b = wave + NMW * i;
+            if (b < NDX) {
+                const int rb = b / KBLK, cb = b - rb * KBLK;
+                const float s = csum[i] + __shfl_xor(csum[i], 32), q = csq[i] + __shfl_xor(csq[i], 32);
+                if (half == 0) { red2[(rb * 2 + 0) * KP + cb * 32 + l31] = s; red2[(rb * 2 + 1) * KP + cb * 32 + l31] = q; }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < p.N) {
+        float t = 0.f;
+        for (int i = 0; i < DROWS; ++i) t += red[i * NP + tid];
+        slab[(size_t)tid * Kout + p.K] = t;
+    }
+    if (p.stat_partial) {
+        for (int e = tid; e < 2 * p.K; e += THREADS) {
+            const int which = e / p.K, c = e - which * p.K;
+            float v = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) v += red2[(rb * 2 + which) * KP + c];
+            p.stat_partial[((size_t)blockIdx.x * 2 + which) * p.K + c] = v;
+        }
+    }
+}
+
+template <int NBLK, int KBLK, int TR>
+constexpr int fs2_lds_bytes() { return (2 * (TR * (32 * NBLK + 4) + TR * (32 * KBLK + 4)) + 32 * NBLK * 32 * KBLK) * 4; }
+
 template <int NBLK, int KBLK>
 constexpr int fb_lds_bytes() { return (FB_ROWS * (32 * NBLK + 4) + FB_ROWS * (32 * KBLK + 4) + 32 * NBLK * 32 * KBLK) * 4; }
 
@@ -579,6 +874,23 @@ int fs_resident_of()
     return cached;
 }
 
+// 128 x 128 layers: general split-role kernel, 32-row tiles, 8 multiplier + 4 staging waves (PN2_TUNE_FB_SPLIT2=0: off)
+bool fs2_applies(int nblk, int kblk) { return nblk == 4 && kblk == 4 && pn2::tune_get("fb_split2", 1) != 0; }
+
+template <bool POOLED>
+int fs2_prepare44()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    constexpr int lds = fs2_lds_bytes<4, 4, 32>();
+    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_split2_kernel<4, 4, POOLED, 32, 8, 4>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_split2_kernel<4, 4, POOLED, 32, 8, 4>, 768, lds) != hipSuccess) return 0;
+    cached = n < 1 ? 0 : 1;
+    return cached;
+}
+
 // split-role kernel: K <= 32 and N <= 64 (PN2_TUNE_FB_SPLIT=0 switches it off)
 bool fs_applies(int nblk, int kblk) { return kblk == 1 && nblk <= 2 && pn2::tune_get("fb_split", 1) != 0; }
 
@@ -617,6 +929,12 @@ PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
     if (M <= 0 || N <= 0 || K <= 0 || N > 128 || K > 128 || (N & 3) || (K & 3)) return 0;
     const int nblk_ = fb_blocks(N), kblk_ = fb_blocks(K);
     int per_cu = fs_applies(nblk_, kblk_) ? fs_resident_rt(nblk_) : fb_resident_rt(nblk_, kblk_);
+    int tile_rows = FB_ROWS;
+    if (fs2_applies(nblk_, kblk_)) {
+        const int a = fs2_prepare44<false>(), b = fs2_prepare44<true>();
+        per_cu = a < b ? a : b;
+        tile_rows = 32;
+    }
     if (per_cu < 1) return 0;
     int cus = 256;
     {
@@ -631,7 +949,7 @@ PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
         }
         cus = cached_cus;
     }
-    const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
+    const int tiles = (M + tile_rows - 1) / tile_rows;
     const int wgs = cus * pn2::tune_get("mlp_fb_wgs", per_cu);
     return tiles < wgs ? tiles : wgs;
 }
@@ -668,7 +986,13 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int nblk = fb_blocks(N), kblk = fb_blocks(K);
     int rc = PN2_ERR_UNSUPPORTED;
-    if (fs_applies(nblk, kblk)) {
+    if (fs2_applies(nblk, kblk)) {
+        if (argk)
+            hipLaunchKernelGGL((mlp_bwd_split2_kernel<4, 4, true, 32, 8, 4>), dim3(P), dim3(768), (fs2_lds_bytes<4, 4, 32>()), stream, a);
+        else
+            hipLaunchKernelGGL((mlp_bwd_split2_kernel<4, 4, false, 32, 8, 4>), dim3(P), dim3(768), (fs2_lds_bytes<4, 4, 32>()), stream, a);
+        rc = PN2_LAUNCH_RC();
+    } else if (fs_applies(nblk, kblk)) {
 #define PN2_FS(NB, PO) hipLaunchKernelGGL((mlp_bwd_split_kernel<NB, PO>), dim3(P), dim3(FB_THREADS), (fs_lds_bytes<NB>()), stream, a)
         if (nblk == 1) { if (argk) PN2_FS(1, true); else PN2_FS(1, false); }
         else { if (argk) PN2_FS(2, true); else PN2_FS(2, false); }
