@@ -874,21 +874,50 @@ int fs_resident_of()
     return cached;
 }
 
-// 128 x 128 layers: general split-role kernel, 32-row tiles, 8 multiplier + 4 staging waves (PN2_TUNE_FB_SPLIT2=0: off)
-bool fs2_applies(int nblk, int kblk) { return nblk == 4 && kblk == 4 && pn2::tune_get("fb_split2", 1) != 0; }
+// General split-role kernel: which shapes use it and with which tile (PN2_TUNE_FB_SPLIT2=0: off; bit 1 = the
+// 128 x 128 layers with 32-row tiles, bit 2 = the 64..128-channel layers of SA2 with 64-row tiles).
+int fs2_tile_rows(int nblk, int kblk)
+{
+    const int m = pn2::tune_get("fb_split2", 1);     // SA2 shapes measured: 72 / 40 / 57 us against 70 / 42 / 60 us: off
+    if (nblk == 4 && kblk == 4) return (m & 1) ? 32 : 0;
+    if ((nblk == 2 && kblk == 2) || (nblk == 4 && kblk == 2) || (nblk == 2 && kblk == 4)) return (m & 2) ? 64 : 0;
+    return 0;
+}
 
-template <bool POOLED>
-int fs2_prepare44()
+template <int NBLK, int KBLK, bool POOLED, int TR>
+int fs2_prepare()
 {
     static int cached = -1;
     if (cached >= 0) return cached;
-    constexpr int lds = fs2_lds_bytes<4, 4, 32>();
-    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_split2_kernel<4, 4, POOLED, 32, 8, 4>);
+    constexpr int lds = fs2_lds_bytes<NBLK, KBLK, TR>();
+    const void *fn = reinterpret_cast<const void *>(&mlp_bwd_split2_kernel<NBLK, KBLK, POOLED, TR, 8, 4>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_split2_kernel<4, 4, POOLED, 32, 8, 4>, 768, lds) != hipSuccess) return 0;
-    cached = n < 1 ? 0 : 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_split2_kernel<NBLK, KBLK, POOLED, TR, 8, 4>, 768, lds) != hipSuccess) return 0;
+    cached = n < 1 ? 0 : 1;                           // one 12-wave workgroup per CU
     return cached;
+}
+
+template <int NBLK, int KBLK, int TR>
+int fs2_resident() { const int a = fs2_prepare<NBLK, KBLK, false, TR>(), b = fs2_prepare<NBLK, KBLK, true, TR>(); return a < b ? a : b; }
+
+int fs2_resident_rt(int nblk, int kblk)
+{
+    if (nblk == 4 && kblk == 4) return fs2_resident<4, 4, 32>();
+    if (nblk == 2 && kblk == 2) return fs2_resident<2, 2, 64>();
+    if (nblk == 4 && kblk == 2) return fs2_resident<4, 2, 64>();
+    if (nblk == 2 && kblk == 4) return fs2_resident<2, 4, 64>();
+    return 0;
+}
+
+template <int NBLK, int KBLK, int TR>
+int fs2_launch(const BwdArgs &a, int grid, hipStream_t stream)
+{
+    if (a.argk)
+        hipLaunchKernelGGL((mlp_bwd_split2_kernel<NBLK, KBLK, true, TR, 8, 4>), dim3(grid), dim3(768), (fs2_lds_bytes<NBLK, KBLK, TR>()), stream, a);
+    else
+        hipLaunchKernelGGL((mlp_bwd_split2_kernel<NBLK, KBLK, false, TR, 8, 4>), dim3(grid), dim3(768), (fs2_lds_bytes<NBLK, KBLK, TR>()), stream, a);
+    return PN2_LAUNCH_RC();
 }
 
 // split-role kernel: K <= 32 and N <= 64 (PN2_TUNE_FB_SPLIT=0 switches it off)
@@ -930,10 +959,9 @@ PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
     const int nblk_ = fb_blocks(N), kblk_ = fb_blocks(K);
     int per_cu = fs_applies(nblk_, kblk_) ? fs_resident_rt(nblk_) : fb_resident_rt(nblk_, kblk_);
     int tile_rows = FB_ROWS;
-    if (fs2_applies(nblk_, kblk_)) {
-        const int a = fs2_prepare44<false>(), b = fs2_prepare44<true>();
-        per_cu = a < b ? a : b;
-        tile_rows = 32;
+    if (fs2_tile_rows(nblk_, kblk_)) {
+        per_cu = fs2_resident_rt(nblk_, kblk_);
+        tile_rows = fs2_tile_rows(nblk_, kblk_);
     }
     if (per_cu < 1) return 0;
     int cus = 256;
@@ -986,12 +1014,11 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int nblk = fb_blocks(N), kblk = fb_blocks(K);
     int rc = PN2_ERR_UNSUPPORTED;
-    if (fs2_applies(nblk, kblk)) {
-        if (argk)
-            hipLaunchKernelGGL((mlp_bwd_split2_kernel<4, 4, true, 32, 8, 4>), dim3(P), dim3(768), (fs2_lds_bytes<4, 4, 32>()), stream, a);
-        else
-            hipLaunchKernelGGL((mlp_bwd_split2_kernel<4, 4, false, 32, 8, 4>), dim3(P), dim3(768), (fs2_lds_bytes<4, 4, 32>()), stream, a);
-        rc = PN2_LAUNCH_RC();
+    if (fs2_tile_rows(nblk, kblk)) {
+        if (nblk == 4 && kblk == 4) rc = fs2_launch<4, 4, 32>(a, P, stream);
+        else if (nblk == 2 && kblk == 2) rc = fs2_launch<2, 2, 64>(a, P, stream);
+        else if (nblk == 4 && kblk == 2) rc = fs2_launch<4, 2, 64>(a, P, stream);
+        else rc = fs2_launch<2, 4, 64>(a, P, stream);
     } else if (fs_applies(nblk, kblk)) {
 #define PN2_FS(NB, PO) hipLaunchKernelGGL((mlp_bwd_split_kernel<NB, PO>), dim3(P), dim3(FB_THREADS), (fs_lds_bytes<NB>()), stream, a)
         if (nblk == 1) { if (argk) PN2_FS(1, true); else PN2_FS(1, false); }
