@@ -1273,6 +1273,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
     }
 }
 
+// Dense form (no pooling, C % 4 == 0): a thread owns 4 columns, 256 threads cover 256 / (C/4 or 32) rows per pass,
+// 4 passes (8 float4 loads) are issued before the first add -- the scalar kernel above pays one memory round trip
+// per row and thread.  blockIdx.y = 128-column slab.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec4_kernel(const float *__restrict__ g, int ldg, const float *__restrict__ z,
+                                                                 int ldz, long long rows, int C, const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift, const float *__restrict__ mean,
+                                                                 const float *__restrict__ invstd, float *__restrict__ partial)
+{
+    __shared__ float4 sS[8][32], sQ[8][32];
+    const int cl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c4 = blockIdx.y * 128 + cl * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (c4 < C) {
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c4), sh = *reinterpret_cast<const float4 *>(shift + c4);
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c4), is = *reinterpret_cast<const float4 *>(invstd + c4);
+        const long long stride = (long long)gridDim.x * 8;
+        for (long long r0 = (long long)blockIdx.x * 8 + ry; r0 < rows; r0 += 4 * stride) {
+            float4 gv[4], zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = r0 + u * stride < rows ? r0 + u * stride : rows - 1;
+                gv[u] = *reinterpret_cast<const float4 *>(g + (size_t)r * ldg + c4);
+                zv[u] = *reinterpret_cast<const float4 *>(z + (size_t)r * ldz + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + u * stride < rows) {
+#define PN2_ACC(f) { const float gh = (sc.f * zv[u].f + sh.f) > 0.f ? gv[u].f : 0.f; s.f += gh; q.f += gh * ((zv[u].f - mu.f) * is.f); }
+                    PN2_ACC(x) PN2_ACC(y) PN2_ACC(z) PN2_ACC(w)
+#undef PN2_ACC
+                }
+            }
+        }
+    }
+    sS[ry][cl] = s;
+    sQ[ry][cl] = q;
+    __syncthreads();
+    if (ry == 0 && c4 < C) {
+        for (int i = 1; i < 8; ++i) {
+            s.x += sS[i][cl].x; s.y += sS[i][cl].y; s.z += sS[i][cl].z; s.w += sS[i][cl].w;
+            q.x += sQ[i][cl].x; q.y += sQ[i][cl].y; q.z += sQ[i][cl].z; q.w += sQ[i][cl].w;
+        }
+        *reinterpret_cast<float4 *>(partial + ((size_t)blockIdx.x * 2 + 0) * C + c4) = s;
+        *reinterpret_cast<float4 *>(partial + ((size_t)blockIdx.x * 2 + 1) * C + c4) = q;
+    }
+}
+
 // partial[P][2][C] -> dbeta = sum gh, dgamma = sum gh*xh, c1 = dbeta/count, c2 = dgamma/count
 __device__ __forceinline__ void bn_bwd_finalize_block(int block, const float *__restrict__ partial, int P, int C, double count,
                                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
@@ -1608,6 +1655,13 @@ PN2_EXPORT int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ld
     PN2_REQUIRE_PTR(partial);
     if (rows <= 0 || C <= 0 || (argk && pool_k <= 0)) return PN2_ERR_SHAPE;
     dim3 grid((unsigned)pn2_bn_bwd_reduce_partials(rows), (unsigned)((C + 31) / 32));
+    if (!argk && C % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && aligned16(g) && aligned16(z) && aligned16(scale) &&
+        aligned16(shift) && aligned16(mean) && aligned16(invstd) && aligned16(partial)) {
+        grid.y = (unsigned)((C + 127) / 128);
+        hipLaunchKernelGGL(bn_bwd_reduce_vec4_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g, ldg, z, ldz, rows,
+                           C, scale, shift, mean, invstd, partial);
+        return PN2_LAUNCH_RC();
+    }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g, ldg, z, ldz, rows,
                        C, argk, pool_k, scale, shift, mean, invstd, partial);
     return PN2_LAUNCH_RC();
