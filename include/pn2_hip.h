@@ -125,7 +125,7 @@ int pn2_three_interpolate_backward(const float *grad_out, const int64_t *idx3, c
  * stat_partial (nullable) [pn2_mlp_gemm_max_partials(M)][2][N]: per-workgroup column sums of out
  * and out^2 (train-mode batch statistics) -- or, when mask_z != NULL (backward), out is first
  * masked by the ReLU of the layer below (mscale*mask_z+mshift > 0) and the sums are those of
- * out and out*(mask_z-mmean)*minvstd (its dbeta / dgamma). */
+ * out and out*(mask_z-mmean)*minvstd (its dbeta / dgamma); mask_z is accepted with prologue 2 only. */
 int pn2_mlp_gemm_max_partials(int M);
 int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
                  const float *scale, const float *shift, const float *mean, const float *invstd,

@@ -56,6 +56,70 @@ struct GemmArgs {
     int ldm;
 };
 
+// Epilogue of one 32x32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half): bias,
+// optionally the ReLU mask of the layer below with its BatchNorm-backward sums, column sums, stores.
+// Every value the rows need is loaded and waited for BEFORE the first store, and a block whose 32 rows are all
+// < M (FULL) stores in straight-line code: vmcnt counts stores too on gfx9, and with a load result first used
+// inside per-row branches the compiler puts s_waitcnt vmcnt(0) in front of every store, i.e. one store
+// acknowledgement round trip per row (16 per block).
+template <bool FULL, bool BWD>
+__device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16 &acc, int row0, int half, int col,
+                                                 float &csum, float &csq)
+{
+    float bv = 0.f;
+    if (p.bias) bv = p.bias[col];
+    const bool second = p.out2 && col >= p.nsplit;
+    float *ob = second ? p.out2 + (col - p.nsplit) : p.out + col;
+    const size_t ld = second ? (size_t)p.ldo2 : (size_t)p.ldo;
+    float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
+    float zp[16];
+    if (BWD) {
+        ms = p.mscale[col]; mh = p.mshift[col]; mm = p.mmean[col]; mi = p.minvstd[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            zp[r] = p.mask_z[(size_t)(FULL ? row : min(row, p.M - 1)) * p.ldm + col];
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // addresses four at a time, not 16 pairs
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(zp[r]));
+        asm volatile("" :: "v"(ms), "v"(mh), "v"(mm), "v"(mi));
+    }
+    asm volatile("" :: "v"(bv));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (FULL || row < p.M) {
+            float z = acc[r] + bv;
+            if (BWD) {
+                z = (ms * zp[r] + mh) > 0.f ? z : 0.f;
+                csum += z;
+                csq += z * ((zp[r] - mm) * mi);
+            } else {
+                csum += z;
+                csq += z * z;
+            }
+            ob[(size_t)row * ld] = z;
+        }
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the next block's loads (16 more registers) behind these stores
+}
+
+template <bool BWD_POSSIBLE>
+__device__ __forceinline__ void gemm_store_block_any(const GemmArgs &p, const f32x16 &acc, int row0, int half, int col,
+                                                     bool bwd_epi, float &csum, float &csq)
+{
+    const bool full = row0 + 32 <= p.M;                       // wave-uniform
+    if (BWD_POSSIBLE && bwd_epi) {
+        if (full) gemm_store_block<true, true>(p, acc, row0, half, col, csum, csq);
+        else gemm_store_block<false, true>(p, acc, row0, half, col, csum, csq);
+    } else {
+        if (full) gemm_store_block<true, false>(p, acc, row0, half, col, csum, csq);
+        else gemm_store_block<false, false>(p, acc, row0, half, col, csum, csq);
+    }
+}
+
 template <int BN, int PRO, bool VEC4>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
 {
@@ -431,6 +495,9 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
         }
         const int t = step / nk, kc = step - t * nk;
         if (kc == nk - 1) {
+            if constexpr (PRO == PRO_BN_BWD) {
+            // dX form: the per-row form below keeps this kernel's register count (the straight-line one costs
+            // 40 more on top of the dz prologue's prefetch registers and spills)
             // ---- epilogue of this tile: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
             const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM;
 #pragma unroll
@@ -468,6 +535,18 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+            }
+            } else {
+            // ---- epilogue of this tile
+            const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * MLP_BM + rw * 32;
+#pragma unroll
+            for (int cb = 0; cb < NBW; ++cb) {
+                const int col = col0 + (cw * NBW + cb) * 32 + l31;
+                if (col < p.N)
+                    gemm_store_block_any<PRO == PRO_BN_BWD>(p, acc[cb], row0, half, col, bwd_epi, csum[cb], csq[cb]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+            }
             }
         }
         if (step + 1 < nsteps) commit(step + 1);                 // into the other LDS half
@@ -654,36 +733,7 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
         const int t = step / nk, kc = step - t * nk;
         if (kc == nk - 1) {
             const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM + rw * 32;
-            if (col < p.N) {
-                const float bv = p.bias ? p.bias[col] : 0.f;
-                float ms = 0.f, mh = 0.f, mm = 0.f, mi = 0.f;
-                float zp[16];
-                if (bwd_epi) {
-                    ms = p.mscale[col]; mh = p.mshift[col]; mm = p.mmean[col]; mi = p.minvstd[col];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        zp[r] = row < p.M ? p.mask_z[(size_t)row * p.ldm + col] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < p.M) {
-                        float z = acc[r] + bv;
-                        if (bwd_epi) {
-                            z = (ms * zp[r] + mh) > 0.f ? z : 0.f;
-                            csum += z;
-                            csq += z * ((zp[r] - mm) * mi);
-                        } else {
-                            csum += z;
-                            csq += z * z;
-                        }
-                        if (p.out2 && col >= p.nsplit) p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] = z;
-                else p.out[(size_t)row * p.ldo + col] = z;
-                    }
-                }
-            }
+            if (col < p.N) gemm_store_block_any<PRO == PRO_BN_BWD>(p, acc, row0, half, col, bwd_epi, csum, csq);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         }
@@ -1445,6 +1495,7 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
         if (prologue == PRO_BN_RELU && (!scale || !shift)) return PN2_ERR_NULL;
     }
     if (mask_z && (!mscale || !mshift || !mmean || !minvstd || ldm < N)) return PN2_ERR_NULL;
+    if (mask_z && prologue != PRO_BN_BWD) return PN2_ERR_SHAPE;      // the masked epilogue belongs to the dX GEMM
     if (M == 0) return PN2_OK;
     GemmArgs a;
     a.x1 = x1; a.x2 = x2; a.ld1 = ld1; a.ld2 = ld2; a.K1 = K1; a.K2 = K2;
