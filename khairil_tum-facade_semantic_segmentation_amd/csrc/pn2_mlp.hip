@@ -576,56 +576,70 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
 // epilogues, statistics and double-buffered staging as mlp_gemm_pipe_kernel.
 // BM = 64: eight waves, 2 row slices x 4 column blocks: half the weight-tile traffic per flop, for shapes
 // that still give every CU a workgroup with 64-row tiles.
-template <int PRO, bool WT, int BM>
+// BK = 64 (BM = 64 only, dynamic LDS): half as many steps, each with twice the MFMA work -- with one 8-wave workgroup
+// per CU (the dz prologue's registers) a 32-wide step (0.85 us of MFMAs per SIMD) is shorter than the global-load
+// latency of the prefetch it is supposed to hide.
+template <int PRO, bool WT, int BM, int BK>
 __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int pool_shift)
 {
     constexpr int BN = 128;
-    constexpr int T = 8 * BM;                         // threads: one float4 of the A chunk each
+    constexpr int T = 8 * BM;                         // threads
     constexpr int RS = BM / 32;                       // 32-row slices
-    constexpr int NBI = (BN * 8) / T;                 // B float4 per thread and chunk
+    constexpr int Q = BK / 4;                         // float4 per staged row
+    constexpr int AI = (BM * Q) / T;                  // A float4 per thread and chunk (1; 2 for BK = 64)
+    constexpr int RPP = T / Q;                        // rows staged per pass
+    constexpr int NBI = (BN * Q) / T;                 // B float4 per thread and chunk
+    constexpr int LD = BK + 4;                        // LDS row pitch (BK + 4: ds_read_b128 stays conflict-free)
+    constexpr int HK = BK / 2;                        // k range of one lane half
     constexpr int LDBT = BN + 4;
-    constexpr int SB_ELEMS = WT ? MLP_BK * LDBT : BN * MLP_LD;
-    constexpr int SA_ELEMS = BM * MLP_LD;
-    __shared__ __attribute__((aligned(16))) float sAbuf[2 * SA_ELEMS];
-    __shared__ __attribute__((aligned(16))) float sBbuf[2 * SB_ELEMS];
+    constexpr int SB_ELEMS = WT ? BK * LDBT : BN * LD;
+    constexpr int SA_ELEMS = BM * LD;
+    static_assert(BK == 32 || (BK == 64 && BM == 64), "tile");
+    extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+    float *sAbuf = rows_lds;                          // [2][SA_ELEMS]
+    float *sBbuf = rows_lds + 2 * SA_ELEMS;           // [2][SB_ELEMS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int col0 = blockIdx.y * BN;
     const int ntiles = (p.M + BM - 1) / BM;
-    const int nk = (p.K + MLP_BK - 1) / MLP_BK;
+    const int nk = (p.K + BK - 1) / BK;
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int nsteps = my_tiles * nk;
     const bool bwd_epi = p.mask_z != nullptr;
-    const int ar = tid >> 3, ac4 = (tid & 7) * 4;           // A staging: row ar (0..BM-1), 4 columns at ac4
+    const int ar = tid / Q, ac4 = (tid % Q) * 4;            // A staging: rows ar + i*RPP, 4 columns at ac4
     const int rw = wave % RS, cw = wave / RS;               // this wave's row slice / 32-column block
 
-    float4 ra, rz, rb[NBI];
-    uchar4 rk;
+    float4 ra[AI], rz[AI], rb[NBI];
+    uchar4 rk[AI];
     float4 cs, ch, cm, ci, cc1, cc2;
-    ra = rz = cs = ch = cm = ci = cc1 = cc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    rk = make_uchar4(255, 255, 255, 255);
+    cs = ch = cm = ci = cc1 = cc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) { ra[i] = rz[i] = cs; rk[i] = make_uchar4(255, 255, 255, 255); }
 
     auto issue = [&](int step) {
         const int t = step / nk, kc = step - t * nk;
-        const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM, k0 = kc * MLP_BK;
+        const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM, k0 = kc * BK;
         const int k = k0 + ac4;
         const bool kok = k < p.K;
-        const int row = row0 + ar;
-        ra = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO == PRO_BN_BWD) { rz = ra; rk = make_uchar4(255, 255, 255, 255); }
-        if (row < p.M && kok) {
-            if (PRO == PRO_BN_BWD) {
-                if (p.argk) {
-                    const int cent = pool_shift >= 0 ? (row >> pool_shift) : row / p.pool_k;
-                    ra = *reinterpret_cast<const float4 *>(p.x1 + (size_t)cent * p.ld1 + k);
-                    rk = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.K1 + k);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = row0 + ar + i * RPP;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PRO == PRO_BN_BWD) { rz[i] = ra[i]; rk[i] = make_uchar4(255, 255, 255, 255); }
+            if (row < p.M && kok) {
+                if (PRO == PRO_BN_BWD) {
+                    if (p.argk) {
+                        const int cent = pool_shift >= 0 ? (row >> pool_shift) : row / p.pool_k;
+                        ra[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)cent * p.ld1 + k);
+                        rk[i] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.K1 + k);
+                    } else {
+                        ra[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k);
+                    }
+                    rz[i] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + k);
                 } else {
-                    ra = *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k);
+                    ra[i] = k < p.K1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k)
+                                     : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k - p.K1));
                 }
-                rz = *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + k);
-            } else {
-                ra = k < p.K1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * p.ld1 + k)
-                              : *reinterpret_cast<const float4 *>(p.x2 + (size_t)row * p.ld2 + (k - p.K1));
             }
         }
         if (PRO != PRO_NONE && kok) {
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
             const int e = tid + i * T;
             rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!WT) {
-                const int r = e >> 3, c4 = (e & 7) * 4;
+                const int r = e / Q, c4 = (e % Q) * 4;
                 if (col0 + r < p.N && k0 + c4 < p.K)
                     rb[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)(col0 + r) * p.ldw + k0 + c4);
             } else {
@@ -655,38 +669,42 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
     };
     auto commit = [&](int step) {
         const int t = step / nk;
-        const int row = ((int)blockIdx.x + t * (int)gridDim.x) * BM + ar;
+        const int row0 = ((int)blockIdx.x + t * (int)gridDim.x) * BM + ar;
         float *sA = sAbuf + (step & 1) * SA_ELEMS;
         float *sB = sBbuf + (step & 1) * SB_ELEMS;
-        float4 v = ra;
-        if (PRO == PRO_BN_RELU) {
-            v.x = fmaxf(cs.x * v.x + ch.x, 0.f);
-            v.y = fmaxf(cs.y * v.y + ch.y, 0.f);
-            v.z = fmaxf(cs.z * v.z + ch.z, 0.f);
-            v.w = fmaxf(cs.w * v.w + ch.w, 0.f);
-            if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (PRO == PRO_BN_BWD) {
-            float4 g = ra;
-            const float4 z = rz;
-            if (p.argk) {
-                const int kk = pool_shift >= 0 ? (row & ((1 << pool_shift) - 1)) : row % p.pool_k;
-                g.x = rk.x == kk ? g.x : 0.f;
-                g.y = rk.y == kk ? g.y : 0.f;
-                g.z = rk.z == kk ? g.z : 0.f;
-                g.w = rk.w == kk ? g.w : 0.f;
-            }
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = row0 + i * RPP;
+            float4 v = ra[i];
+            if (PRO == PRO_BN_RELU) {
+                v.x = fmaxf(cs.x * v.x + ch.x, 0.f);
+                v.y = fmaxf(cs.y * v.y + ch.y, 0.f);
+                v.z = fmaxf(cs.z * v.z + ch.z, 0.f);
+                v.w = fmaxf(cs.w * v.w + ch.w, 0.f);
+                if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (PRO == PRO_BN_BWD) {
+                float4 g = ra[i];
+                const float4 z = rz[i];
+                if (p.argk) {
+                    const int kk = pool_shift >= 0 ? (row & ((1 << pool_shift) - 1)) : row % p.pool_k;
+                    g.x = rk[i].x == kk ? g.x : 0.f;
+                    g.y = rk[i].y == kk ? g.y : 0.f;
+                    g.z = rk[i].z == kk ? g.z : 0.f;
+                    g.w = rk[i].w == kk ? g.w : 0.f;
+                }
 #define PN2_DZ(f) v.f = cs.f * (((cs.f * z.f + ch.f) > 0.f ? g.f : 0.f) - cc1.f - (z.f - cm.f) * ci.f * cc2.f)
-            PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+                PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
 #undef PN2_DZ
-            if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4 *>(&sA[(ar + i * RPP) * LD + ac4]) = v;
         }
-        *reinterpret_cast<float4 *>(&sA[ar * MLP_LD + ac4]) = v;
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
             const int e = tid + i * T;
             if (!WT) {
-                const int r = e >> 3, c4 = (e & 7) * 4;
-                *reinterpret_cast<float4 *>(&sB[r * MLP_LD + c4]) = rb[i];
+                const int r = e / Q, c4 = (e % Q) * 4;
+                *reinterpret_cast<float4 *>(&sB[r * LD + c4]) = rb[i];
             } else {
                 const int kk = e / (BN / 4), c4 = (e - kk * (BN / 4)) * 4;
                 *reinterpret_cast<float4 *>(&sB[kk * LDBT + c4]) = rb[i];
@@ -709,20 +727,20 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
         if (step + 1 < nsteps) issue(step + 1);
         const float *sA = sAbuf + (step & 1) * SA_ELEMS;
         const float *sB = sBbuf + (step & 1) * SB_ELEMS;
-        const float *aRow = &sA[(rw * 32 + l31) * MLP_LD + 16 * half];
+        const float *aRow = &sA[(rw * 32 + l31) * LD + HK * half];
         // Operand read-ahead (left alone, the compiler puts every LDS read right in front of its consumer:
         // read -> wait -> MFMAs).  Not in mlp_gemm_pipe_kernel: its 8-wave form has no registers to spare.
         auto load_b = [&](int q) -> float4 {
-            if (!WT) return *reinterpret_cast<const float4 *>(&sB[(cw * 32 + l31) * MLP_LD + 16 * half + 4 * q]);
-            const float *bp = &sB[(16 * half + 4 * q) * LDBT + cw * 32 + l31];
+            if (!WT) return *reinterpret_cast<const float4 *>(&sB[(cw * 32 + l31) * LD + HK * half + 4 * q]);
+            const float *bp = &sB[(HK * half + 4 * q) * LDBT + cw * 32 + l31];
             return make_float4(bp[0], bp[LDBT], bp[2 * LDBT], bp[3 * LDBT]);
         };
         float4 a4 = *reinterpret_cast<const float4 *>(aRow);
         float4 b4 = load_b(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < HK / 4; ++q) {
             float4 an = a4, bn = b4;
-            if (q + 1 < 4) { an = *reinterpret_cast<const float4 *>(aRow + 4 * (q + 1)); bn = load_b(q + 1); }
+            if (q + 1 < HK / 4) { an = *reinterpret_cast<const float4 *>(aRow + 4 * (q + 1)); bn = load_b(q + 1); }
             __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
@@ -1526,8 +1544,22 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
             const long long wgs64 = (long long)((M + 63) / 64) * ((N + 127) / 128);
             const bool rows64 = (gx % 2 == 0) && wgs64 >= pn2::tune_get("mlp_rows64_min_wgs", 256) && pn2::tune_get("mlp_rows64", 1);
             if (rows64) grid.x = (unsigned)(gx / 2);
-#define PN2_R32(P, W) do { if (rows64) hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 64>), grid, dim3(512), 0, stream, a, pool_shift); \
-                           else hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 32>), grid, dim3(256), 0, stream, a, pool_shift); } while (0)
+            // 64-wide K steps for the long reductions of the 64-row form (dynamic LDS: 100 KB)
+            const bool bk64 = rows64 && a.K >= 128 && ((pn2::tune_get("mlp_rows_bk64", 4) >> prologue) & 1);
+            constexpr size_t LDS32_64 = 2 * (64 * 36 + 128 * 36) * sizeof(float), LDS32_32 = 2 * (32 * 36 + 128 * 36) * sizeof(float);
+            constexpr size_t LDS64_N = 2 * (64 * 68 + 128 * 68) * sizeof(float), LDS64_T = 2 * (64 * 68 + 64 * 132) * sizeof(float);
+#define PN2_R32(P, W) do { \
+        if (bk64) { \
+            static bool attr_done = false; \
+            if (!attr_done) { \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_gemm_rows32_kernel<P, W, 64, 64>), \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                if (e != hipSuccess) return (int)e; \
+                attr_done = true; \
+            } \
+            hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 64, 64>), grid, dim3(512), (W) ? LDS64_T : LDS64_N, stream, a, pool_shift); \
+        } else if (rows64) hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 64, 32>), grid, dim3(512), LDS32_64, stream, a, pool_shift); \
+        else hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 32, 32>), grid, dim3(256), LDS32_32, stream, a, pool_shift); } while (0)
             if (prologue == PRO_NONE) { if (a.wt) PN2_R32(PRO_NONE, true); else PN2_R32(PRO_NONE, false); }
             else if (prologue == PRO_BN_RELU) { if (a.wt) PN2_R32(PRO_BN_RELU, true); else PN2_R32(PRO_BN_RELU, false); }
             else { if (a.wt) PN2_R32(PRO_BN_BWD, true); else PN2_R32(PRO_BN_BWD, false); }
