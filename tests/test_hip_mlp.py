@@ -55,6 +55,8 @@ CASES = [
     (1000, 64, 256, (256, 128), 0),              # FP2: two sources, ragged M
     (640, 128, 0, (128, 128, 128), 0),           # FP1
     (96, 7, 5, (20, 36), 8),                     # everything ragged / tiny
+    (66017, 16, 0, (32, 64), 0),                 # 128-row pipelined tiles, last tile / last 32-row block ragged
+    (16408, 128, 0, (256, 256), 0),              # 64-row tiles (64-wide K steps in the dX GEMM), ragged
 ]
 
 
@@ -63,7 +65,13 @@ def test_stack_train_forward_backward(env, M, K1, K2, widths, pool_k):
     import copy
     torch, mlp = env
     convs, bns = make_stack(torch, K1 + K2, widths, seed=M + K1)
-    rconvs, rbns = copy.deepcopy(convs).cuda().train(), copy.deepcopy(bns).cuda().train()
+    # Large M: the reference runs in float64.  torch's fp32 batch statistics are off by ~3e-6 (relative) at
+    # such sizes, which flips the ReLU of a handful of the 2 M activations and with it whole rows of dx; against
+    # exact statistics only elements within rounding of the threshold can flip (a few per case), so those cases are
+    # judged by the relative Frobenius error plus a bound on the share of deviating elements.
+    big = M > 10000
+    rdt = torch.float64 if big else torch.float32
+    rconvs, rbns = copy.deepcopy(convs).cuda().train().to(rdt), copy.deepcopy(bns).cuda().train().to(rdt)
     convs, bns = convs.cuda().train(), bns.cuda().train()
     g = torch.Generator().manual_seed(1)
     x = torch.randn(M, K1 + K2, generator=g).cuda()
@@ -72,22 +80,30 @@ def test_stack_train_forward_backward(env, M, K1, K2, widths, pool_k):
         x[1] = x[0]
     x1 = x[:, :K1].contiguous().requires_grad_(True)
     x2 = x[:, K1:].contiguous().requires_grad_(True) if K2 else None
-    xr = x.clone().requires_grad_(True)
+    xr = x.clone().to(rdt).requires_grad_(True)
+
+    def close(a, b, what, tol=2e-3):
+        b = b.to(torch.float64)
+        d = (a.to(torch.float64) - b).abs()
+        s = float(b.abs().max()) + 1e-6
+        if big:
+            # one flipped ReLU (an activation within rounding of 0: ~1e-6 of the 4 M elements) moves a whole row of
+            # dx / dW by O(|g| |a|), far above the element tolerance
+            assert float(d.norm() / (b.norm() + 1e-30)) <= tol, (what, "fro", float(d.norm() / b.norm()))
+            if d.numel() >= 10000:
+                assert float((d > tol * s + 1e-5).double().mean()) <= 5e-3, (what, "share of deviating elements")
+        else:
+            assert float(d.max()) <= tol * s + 1e-5, (what, float(d.max()), s)
 
     y = mlp.mlp_stack(x1, x2, convs, bns, pool_k)
     yr = torch_reference(torch, xr, rconvs, rbns, pool_k)
     assert y.shape == yr.shape
-    scale = float(yr.detach().abs().max()) + 1e-6
-    assert float((y - yr).detach().abs().max()) <= 2e-4 * scale + 1e-5
+    close(y.detach(), yr.detach(), "y", 2e-4)
 
     go = torch.randn(y.shape, generator=g).cuda()
     y.backward(go)
-    yr.backward(go)
+    yr.backward(go.to(rdt))
     gx = x1.grad if x2 is None else torch.cat([x1.grad, x2.grad], dim=1)
-    def close(a, b, what):
-        s = float(b.abs().max()) + 1e-6
-        err = float((a - b).abs().max())
-        assert err <= 2e-3 * s + 1e-5, (what, err, s)
     close(gx, xr.grad, "dx")
     for l, (c, rc, b, rb) in enumerate(zip(convs, rconvs, bns, rbns)):
         close(c.weight.grad, rc.weight.grad, "dW%d" % l)
