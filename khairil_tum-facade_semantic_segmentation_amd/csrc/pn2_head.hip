@@ -82,14 +82,25 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
         if (j < C) sL[r][j] = acc[i] + (bias ? bias[j] : 0.f);
     }
     __syncthreads();
-    if (tid < HD_ROWS && row0 + tid < M) {
-        float mx = sL[tid][0];
-        for (int j = 1; j < C; ++j) mx = fmaxf(mx, sL[tid][j]);
-        float s = 0.f;
-        for (int j = 0; j < C; ++j) s += expf(sL[tid][j] - mx);
-        const float lse = mx + logf(s);
-        float *o = logp + (size_t)(row0 + tid) * C;
-        for (int j = 0; j < C; ++j) o[j] = sL[tid][j] - lse;
+    {   // log-softmax: 4 lanes per row (classes part, part+4, ...), then the [rows][C] tile leaves coalesced
+        const int rr = tid >> 2, part = tid & 3;
+        float mx = -INFINITY;
+        for (int j = part; j < C; j += 4) mx = fmaxf(mx, sL[rr][j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float sum = 0.f;
+        for (int j = part; j < C; j += 4) sum += expf(sL[rr][j] - mx);
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float lse = mx + logf(sum);
+        for (int j = part; j < C; j += 4) sL[rr][j] -= lse;
+    }
+    __syncthreads();
+    const int nout = min(HD_ROWS, M - row0) * C;
+    float *o = logp + (size_t)row0 * C;
+    for (int e = tid; e < nout; e += HD_THREADS) {
+        const int rr = e / C;
+        o[e] = sL[rr][e - rr * C];
     }
 }
 
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
     __shared__ __attribute__((aligned(16))) float sD[HD_ROWS][HD_CMAX];
+    __shared__ float sG[HD_ROWS * HD_CMAX], sP[HD_ROWS * HD_CMAX];      // g / logp rows of the tile, pitch C
     const int tid = threadIdx.x;
     const int k4n = K >> 2;
     const int ntiles = (M + HD_ROWS - 1) / HD_ROWS;
@@ -125,21 +137,40 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * HD_ROWS;
         __syncthreads();                                      // previous tile's readers are done (also covers sW)
-        stage_rows(y, ldy, row0, M, k4n, sY, tid);
-        if (tid < HD_ROWS) {
-            const int row = row0 + tid;
-            float gs = 0.f;
-            if (row < M)
-                for (int j = 0; j < C; ++j) gs += g[(size_t)row * C + j];
-            for (int j = 0; j < HD_CMAX; ++j) {
-                float d = 0.f;
-                if (row < M && j < C) d = g[(size_t)row * C + j] - expf(logp[(size_t)row * C + j]) * gs;
-                sD[tid][j] = d;
+        // g / logp rows of the tile: [rows][C] contiguous, loaded coalesced and unconditionally (clamped), in flight
+        // together with the feature rows
+        constexpr int NG = HD_ROWS * HD_CMAX / HD_THREADS;           // 8
+        const int nin = min(HD_ROWS, M - row0) * C;
+        float gv[NG], lv[NG];
+        {
+            const float *gt = g + (size_t)row0 * C, *lt = logp + (size_t)row0 * C;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int e = min(tid + i * HD_THREADS, nin - 1);
+                gv[i] = gt[e];
+                lv[i] = lt[e];
             }
+        }
+        stage_rows(y, ldy, row0, M, k4n, sY, tid);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = tid + i * HD_THREADS;
+            if (e < HD_ROWS * C) { sG[e] = e < nin ? gv[i] : 0.f; sP[e] = e < nin ? lv[i] : 0.f; }
+        }
+        __syncthreads();
+        {   // dz = g - exp(logp) * sum_j g_j: 4 lanes per row
+            const int rr = tid >> 2, part = tid & 3;
+            float gs = 0.f;
+            for (int j = part; j < C; j += 4) gs += sG[rr * C + j];
+            gs += __shfl_xor(gs, 1);
+            gs += __shfl_xor(gs, 2);
+            for (int j = part; j < HD_CMAX; j += 4)
+                sD[rr][j] = j < C ? sG[rr * C + j] - expf(sP[rr * C + j]) * gs : 0.f;     // rows >= M: g = 0 -> dz = 0
         }
         __syncthreads();
         if (gy && gk4 < K) {
-#pragma unroll
+            const bool full = row0 + HD_ROWS <= M;            // straight-line stores: a branch per row makes the
+#pragma unroll                                                // compiler wait for each store's acknowledgement
             for (int i = 0; i < HD_ROWS / 8; ++i) {
                 const int r = gr0 + 8 * i;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
                     a.z = fmaf(d, b.z, a.z);
                     a.w = fmaf(d, b.w, a.w);
                 }
-                if (row0 + r < M) *reinterpret_cast<float4 *>(&gy[(size_t)(row0 + r) * ldgy + gk4]) = a;
+                if (full || row0 + r < M) *reinterpret_cast<float4 *>(&gy[(size_t)(row0 + r) * ldgy + gk4]) = a;
             }
         }
         if (wj0 < C) {                                        // uniform per wave
