@@ -794,6 +794,33 @@ __device__ __forceinline__ void strided_sum_any(const float *__restrict__ base, 
     }
 }
 
+// the same for two interleaved series (sum and sum of squares of one channel) in ONE memory round trip
+template <int NJ>
+__device__ __forceinline__ void strided_sum_pair(const float *__restrict__ a, const float *__restrict__ b, size_t stride, int py,
+                                                 int P, float &a0, float &a1, float &b0, float &b1)
+{
+    float va[NJ], vb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const size_t o = (size_t)min(py + 32 * j, P - 1) * stride;
+        va[j] = a[o];
+        vb[j] = b[o];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (py + 32 * j < P) { if (j & 1) { a1 += va[j]; b1 += vb[j]; } else { a0 += va[j]; b0 += vb[j]; } }
+}
+__device__ __forceinline__ void strided_sum_pair_any(const float *__restrict__ a, const float *__restrict__ b, size_t stride,
+                                                     int py, int P, float &a0, float &a1, float &b0, float &b1)
+{
+    if (P <= 32) strided_sum_pair<1>(a, b, stride, py, P, a0, a1, b0, b1);
+    else if (P <= 64) strided_sum_pair<2>(a, b, stride, py, P, a0, a1, b0, b1);
+    else if (P <= 128) strided_sum_pair<4>(a, b, stride, py, P, a0, a1, b0, b1);
+    else if (P <= 256) strided_sum_pair<8>(a, b, stride, py, P, a0, a1, b0, b1);
+    else if (P <= 512) strided_sum_pair<16>(a, b, stride, py, P, a0, a1, b0, b1);
+    else { strided_sum_any(a, stride, py, P, a0, a1); strided_sum_any(b, stride, py, P, b0, b1); }
+}
+
 // partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
 // :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
 // estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
@@ -810,12 +837,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 32 partial slices
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
+    // the layer parameters travel with the partials (one memory round trip for the whole kernel, which runs 22
+    // times per step), not after the reduction
+    const int cc = min(c, C - 1);
+    const float g = gamma ? gamma[cc] : 1.0f, b = beta ? beta[cc] : 0.0f;
+    const float rm = running_mean ? running_mean[cc] : 0.f, rv = running_var ? running_var[cc] : 0.f;
     if (c < C) {
         // a thread's partials are all loaded before the first add: the loads are independent, a load-add loop
-        // would pay one memory round trip per iteration (this kernel runs 22 times per step)
+        // would pay one memory round trip per iteration
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;            // <= 8 terms each: fp32 is exact enough here
-        strided_sum_any(partial + c, (size_t)2 * C, py, P, s0, s1);
-        strided_sum_any(partial + C + c, (size_t)2 * C, py, P, q0, q1);
+        strided_sum_pair_any(partial + c, partial + C + c, (size_t)2 * C, py, P, s0, s1, q0, q1);
         s = (double)s0 + (double)s1;
         q = (double)q0 + (double)q1;
     }
@@ -828,15 +859,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
     scale[c] = g * invstd;
     shift[c] = b - (float)mean * g * invstd;
     if (mean_out) mean_out[c] = (float)mean;
     if (invstd_out) invstd_out[c] = invstd;
-    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_mean) running_mean[c] = (1.0f - momentum) * rm + momentum * (float)mean;
     if (running_var) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
     }
 }
 
@@ -1399,8 +1429,7 @@ __device__ __forceinline__ void bn_bwd_finalize_block(int block, const float *__
     double s = 0.0, q = 0.0;
     if (c < C) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-        strided_sum_any(partial + c, (size_t)2 * C, py, P, s0, s1);
-        strided_sum_any(partial + C + c, (size_t)2 * C, py, P, q0, q1);
+        strided_sum_pair_any(partial + c, partial + C + c, (size_t)2 * C, py, P, s0, s1, q0, q1);
         s = (double)s0 + (double)s1;
         q = (double)q0 + (double)q1;
     }
