@@ -568,8 +568,17 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
     const bool masked = p.ascale != nullptr;
     const int G = gridDim.x;
     const int t0 = blockIdx.x;                        // < ntiles (the grid never exceeds the tile count)
-    const int Kout = p.K + 1;
-    float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout;
+    // Layers with more than KP inputs: blockIdx.y selects a block of KP input columns; the workgroup then solves the
+    // same problem on the column slice (x, W, dX, dW and the statistics of the layer below are all per input column;
+    // g and z are read once per block).
+    const int k0 = (int)blockIdx.y * KP, Ktot = p.K;
+    p.K = min(KP, Ktot - k0);
+    p.x += k0;
+    p.w += k0;
+    if (p.gp) p.gp += k0;
+    if (masked) { p.ascale += k0; p.ashift += k0; p.amean += k0; p.ainvstd += k0; }
+    const int Kout = Ktot + 1;
+    float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout + k0;
 
     for (int e = tid; e < NP * (KP / 4); e += THREADS) {
         const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
@@ -807,10 +816,10 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
         }
     }
     __syncthreads();
-    if (tid < p.N) {
+    if (tid < p.N && blockIdx.y == 0) {
         float t = 0.f;
         for (int i = 0; i < DROWS; ++i) t += red[i * NP + tid];
-        slab[(size_t)tid * Kout + p.K] = t;
+        slab[(size_t)tid * Kout + Ktot] = t;
     }
     if (p.stat_partial) {
         for (int e = tid; e < 2 * p.K; e += THREADS) {
@@ -818,7 +827,7 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
             float v = 0.f;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) v += red2[(rb * 2 + which) * KP + c];
-            p.stat_partial[((size_t)blockIdx.x * 2 + which) * p.K + c] = v;
+            p.stat_partial[((size_t)blockIdx.x * 2 + which) * Ktot + k0 + c] = v;
         }
     }
 }
@@ -911,12 +920,12 @@ int fs2_resident_rt(int nblk, int kblk)
 }
 
 template <int NBLK, int KBLK, int TR>
-int fs2_launch(const BwdArgs &a, int grid, hipStream_t stream)
+int fs2_launch(const BwdArgs &a, int grid, hipStream_t stream, int kblocks = 1)
 {
     if (a.argk)
-        hipLaunchKernelGGL((mlp_bwd_split2_kernel<NBLK, KBLK, true, TR, 8, 4>), dim3(grid), dim3(768), (fs2_lds_bytes<NBLK, KBLK, TR>()), stream, a);
+        hipLaunchKernelGGL((mlp_bwd_split2_kernel<NBLK, KBLK, true, TR, 8, 4>), dim3(grid, kblocks), dim3(768), (fs2_lds_bytes<NBLK, KBLK, TR>()), stream, a);
     else
-        hipLaunchKernelGGL((mlp_bwd_split2_kernel<NBLK, KBLK, false, TR, 8, 4>), dim3(grid), dim3(768), (fs2_lds_bytes<NBLK, KBLK, TR>()), stream, a);
+        hipLaunchKernelGGL((mlp_bwd_split2_kernel<NBLK, KBLK, false, TR, 8, 4>), dim3(grid, kblocks), dim3(768), (fs2_lds_bytes<NBLK, KBLK, TR>()), stream, a);
     return PN2_LAUNCH_RC();
 }
 
@@ -955,8 +964,10 @@ int fb_launch(const BwdArgs &a, int grid, hipStream_t stream)
 // Number of partial slabs (= workgroups) pn2_mlp_bwd_layer uses, 0 if the shape is not covered.
 PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
 {
-    if (M <= 0 || N <= 0 || K <= 0 || N > 128 || K > 128 || (N & 3) || (K & 3)) return 0;
-    const int nblk_ = fb_blocks(N), kblk_ = fb_blocks(K);
+    if (M <= 0 || N <= 0 || K <= 0 || N > 128 || (N & 3) || (K & 3)) return 0;
+    // more than 128 inputs: 128-column blocks of the 128 x 128 split-role kernel (65..128 outputs only)
+    if (K > 128 && !(N > 64 && fs2_tile_rows(4, 4) && pn2::tune_get("fb_kblocks", 1))) return 0;
+    const int nblk_ = fb_blocks(N), kblk_ = fb_blocks(K > 128 ? 128 : K);
     int per_cu = fs_applies(nblk_, kblk_) ? fs_resident_rt(nblk_) : fb_resident_rt(nblk_, kblk_);
     int tile_rows = FB_ROWS;
     if (fs2_tile_rows(nblk_, kblk_)) {
@@ -1012,10 +1023,10 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     a.stat_partial = stat_partial; a.dw_partial = dw_partial; a.M = M; a.N = N; a.K = K;
     a.dbg = pn2::tune_get("fb_dbg", 0);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int nblk = fb_blocks(N), kblk = fb_blocks(K);
+    const int nblk = fb_blocks(N), kblk = fb_blocks(K > 128 ? 128 : K);
     int rc = PN2_ERR_UNSUPPORTED;
     if (fs2_tile_rows(nblk, kblk)) {
-        if (nblk == 4 && kblk == 4) rc = fs2_launch<4, 4, 32>(a, P, stream);
+        if (nblk == 4 && kblk == 4) rc = fs2_launch<4, 4, 32>(a, P, stream, (K + 127) / 128);
         else if (nblk == 2 && kblk == 2) rc = fs2_launch<2, 2, 64>(a, P, stream);
         else if (nblk == 4 && kblk == 2) rc = fs2_launch<4, 2, 64>(a, P, stream);
         else rc = fs2_launch<2, 4, 64>(a, P, stream);

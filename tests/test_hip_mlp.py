@@ -55,6 +55,8 @@ CASES = [
     (1000, 64, 256, (256, 128), 0),              # FP2: two sources, ragged M
     (640, 128, 0, (128, 128, 128), 0),           # FP1
     (96, 7, 5, (20, 36), 8),                     # everything ragged / tiny
+    (3000, 132, 0, (128, 128), 0),               # one-pass backward over two blocks of input columns (128 + 4), ragged
+    (2500, 64, 0, (256, 128), 0),                # ... 256 inputs with the statistics of the layer below
     (66017, 16, 0, (32, 64), 0),                 # 128-row pipelined tiles, last tile / last 32-row block ragged
     (16408, 128, 0, (256, 256), 0),              # 64-row tiles (64-wide K steps in the dX GEMM), ragged
 ]
