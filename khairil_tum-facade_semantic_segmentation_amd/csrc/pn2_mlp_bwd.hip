@@ -989,7 +989,17 @@ PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
         cus = cached_cus;
     }
     const int tiles = (M + tile_rows - 1) / tile_rows;
-    const int wgs = cus * pn2::tune_get("mlp_fb_wgs", per_cu);
+    int wgs = cus * pn2::tune_get("mlp_fb_wgs", per_cu);
+    if (K > 128) {
+        // column-blocked launch: the blocks' workgroups share the CUs, and every workgroup stages its weight slice
+        // (64 KB) before its first tile -- keep at least two tiles per workgroup
+        const int kb = (K + 127) / 128;
+        int per_block = wgs / kb;
+        const int by_tiles = tiles / pn2::tune_get("fb_kb_min_tiles", 2);
+        if (per_block > by_tiles) per_block = by_tiles;
+        if (per_block < 1) per_block = 1;
+        wgs = per_block;
+    }
     return tiles < wgs ? tiles : wgs;
 }
 
