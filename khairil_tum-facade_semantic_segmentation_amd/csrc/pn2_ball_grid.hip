@@ -227,18 +227,34 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
         const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
         const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
-        for (int z = z0; z <= z1; ++z) {
-            for (int y = y0; y <= y1; ++y) {
-                const int base = (z * Gy + y) * Gx;
-                const int e = (int)start[base + x1 + 1];
-                for (int j = (int)start[base + x0] + l16; j < e; j += 16) {
-                    const float4 p = sP[j];
-                    const float d = pn2::pair_sqdist(cx, cy, cz, cn, p.x, p.y, p.z, p.w);
-                    if (!(d > r2)) {                               // reference :102 masks d > r^2
-                        const unsigned i = sI[j];
-                        atomicOr(&mybm[i >> 5], 1u << (i & 31u));
-                    }
-                }
+        // The (up to) 9 runs as ONE index space: all 18 range reads are in flight together and the 16 lanes walk
+        // the concatenation (ceil(total / 16) steps instead of a partly filled last step per run).
+        int off[9], cum[9];
+        int tot = 0;
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int z = z0 + dz, y = y0 + dy;
+                const bool ok = z <= z1 && y <= y1;
+                const int base = ((ok ? z : z0) * Gy + (ok ? y : y0)) * Gx;
+                const int rs = (int)start[base + x0], re = (int)start[base + x1 + 1];
+                off[dz * 3 + dy] = rs - tot;                   // slot = off + position inside the concatenation
+                tot += ok ? re - rs : 0;
+                cum[dz * 3 + dy] = tot;
+            }
+        }
+#pragma unroll 2
+        for (int pos = l16; pos < tot; pos += 16) {
+            int o = off[8];
+#pragma unroll
+            for (int i = 7; i >= 0; --i) o = pos < cum[i] ? off[i] : o;
+            const int j = o + pos;
+            const float4 p = sP[j];
+            const float d = pn2::pair_sqdist(cx, cy, cz, cn, p.x, p.y, p.z, p.w);
+            if (!(d > r2)) {                                   // reference :102 masks d > r^2
+                const unsigned i = sI[j];
+                atomicOr(&mybm[i >> 5], 1u << (i & 31u));
             }
         }
     }
