@@ -594,7 +594,7 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
     constexpr int LDBT = BN + 4;
     constexpr int SB_ELEMS = WT ? BK * LDBT : BN * LD;
     constexpr int SA_ELEMS = BM * LD;
-    static_assert(BK == 32 || (BK == 64 && BM == 64), "tile");
+    static_assert(BK == 32 || BK == 64, "tile");
     extern __shared__ __attribute__((aligned(16))) float rows_lds[];
     float *sAbuf = rows_lds;                          // [2][SA_ELEMS]
     float *sBbuf = rows_lds + 2 * SA_ELEMS;           // [2][SB_ELEMS]
@@ -1575,24 +1575,34 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
             if (rows64) grid.x = (unsigned)(gx / 2);
             // 64-wide K steps for the long reductions of the 64-row form (dynamic LDS: 100 KB)
             const bool bk64 = rows64 && a.K >= 128 && ((pn2::tune_get("mlp_rows_bk64", 4) >> prologue) & 1);
+            // 32-row tiles (M <= 4096: at most one workgroup per CU, every step pays the full load latency): 64-wide
+            // steps as well when the reduction is long enough
+            const bool bk64s = !rows64 && a.K >= 256 && ((pn2::tune_get("mlp_rows32_bk64", 7) >> prologue) & 1);
             constexpr size_t LDS32_64 = 2 * (64 * 36 + 128 * 36) * sizeof(float), LDS32_32 = 2 * (32 * 36 + 128 * 36) * sizeof(float);
             constexpr size_t LDS64_N = 2 * (64 * 68 + 128 * 68) * sizeof(float), LDS64_T = 2 * (64 * 68 + 64 * 132) * sizeof(float);
-#define PN2_R32(P, W) do { \
-        if (bk64) { \
+            constexpr size_t LDS64S_N = 2 * (32 * 68 + 128 * 68) * sizeof(float), LDS64S_T = 2 * (32 * 68 + 64 * 132) * sizeof(float);
+#define PN2_R32_ATTR(KERNEL) do { \
             static bool attr_done = false; \
             if (!attr_done) { \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_gemm_rows32_kernel<P, W, 64, 64>), \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 if (e != hipSuccess) return (int)e; \
                 attr_done = true; \
-            } \
+            } } while (0)
+#define PN2_R32(P, W) do { \
+        if (bk64) { \
+            PN2_R32_ATTR((mlp_gemm_rows32_kernel<P, W, 64, 64>)); \
             hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 64, 64>), grid, dim3(512), (W) ? LDS64_T : LDS64_N, stream, a, pool_shift); \
         } else if (rows64) hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 64, 32>), grid, dim3(512), LDS32_64, stream, a, pool_shift); \
-        else hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 32, 32>), grid, dim3(256), LDS32_32, stream, a, pool_shift); } while (0)
+        else if (bk64s) { \
+            PN2_R32_ATTR((mlp_gemm_rows32_kernel<P, W, 32, 64>)); \
+            hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 32, 64>), grid, dim3(256), (W) ? LDS64S_T : LDS64S_N, stream, a, pool_shift); \
+        } else hipLaunchKernelGGL((mlp_gemm_rows32_kernel<P, W, 32, 32>), grid, dim3(256), LDS32_32, stream, a, pool_shift); } while (0)
             if (prologue == PRO_NONE) { if (a.wt) PN2_R32(PRO_NONE, true); else PN2_R32(PRO_NONE, false); }
             else if (prologue == PRO_BN_RELU) { if (a.wt) PN2_R32(PRO_BN_RELU, true); else PN2_R32(PRO_BN_RELU, false); }
             else { if (a.wt) PN2_R32(PRO_BN_BWD, true); else PN2_R32(PRO_BN_BWD, false); }
 #undef PN2_R32
+#undef PN2_R32_ATTR
             return PN2_LAUNCH_RC();
         }
     }
