@@ -94,7 +94,6 @@ def main():
     from khairil_tum_facade_semantic_segmentation_amd import _lib, ops, synth
     from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
     from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
-    from oracle import pn2_oracle as orc
     _lib.load()
 
     # synthetic blocks of this rank (weak scaling: 16 blocks per GPU), resident in HBM
@@ -102,8 +101,8 @@ def main():
                                            NUM_CLASSES)
     x = torch.from_numpy(np.ascontiguousarray(blocks.transpose(0, 2, 1))).to(dev)     # [B,C,N]
     y = torch.from_numpy(labels).to(dev)
-    filled = synth.fill_state_dict(orc.state_shapes(NUM_CLASSES, CHANNELS - 6))
     model = M.get_model(NUM_CLASSES, CHANNELS - 6)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     model = model.to(dev)
     trainer = SemSegTrainer(model, class_weight=torch.ones(NUM_CLASSES, device=dev), graphs=not args.no_graphs,
