@@ -286,6 +286,117 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     if (tid < C) slab[(size_t)tid * (K + 1) + K] = dba;
 }
 
+// K = 128: both products of the backward on the matrix cores.  Per 64-row tile wave w owns feature columns
+// [32 w, 32 w + 32): gy = dz * W as two 32 x 32 blocks (reduction over the 32 zero-padded classes, 16 MFMAs each) and
+// its 32 x 32 block of dW = dz^T * y (reduction over the tile's 64 rows, 32 MFMAs), accumulated in registers over
+// the workgroup's tiles.
+constexpr int HD_LDD = HD_CMAX + 4;
+
+__global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
+    const float *__restrict__ g, const float *__restrict__ logp, const float *__restrict__ y, int ldy,
+    const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int C)
+{
+    __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
+    __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_LDW];
+    __shared__ __attribute__((aligned(16))) float sD[HD_ROWS * HD_LDD];
+    __shared__ float sG[HD_ROWS * HD_CMAX], sP[HD_ROWS * HD_CMAX];      // g / logp rows of the tile, pitch C
+    constexpr int K = HD_KMAX, k4n = HD_KMAX / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (M + HD_ROWS - 1) / HD_ROWS;
+    for (int e = tid; e < HD_CMAX * k4n; e += HD_THREADS) {
+        const int j = e / k4n, q = e - j * k4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < C) v = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
+        *reinterpret_cast<float4 *>(&sW[j * HD_LDW + 4 * q]) = v;
+    }
+    hd_f32x16 accW;                                           // dW[class][32 wave + (lane & 31)]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[r] = 0.f;
+    float dba = 0.f;                                          // tid < HD_CMAX: db of class tid
+    const int col = wave * 32 + l31;                          // this lane's feature column
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * HD_ROWS;
+        __syncthreads();                                      // previous tile's readers are done (also covers sW)
+        constexpr int NG = HD_ROWS * HD_CMAX / HD_THREADS;           // 8
+        const int nin = min(HD_ROWS, M - row0) * C;
+        float gv[NG], lv[NG];
+        {
+            const float *gt = g + (size_t)row0 * C, *lt = logp + (size_t)row0 * C;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int e = min(tid + i * HD_THREADS, nin - 1);
+                gv[i] = gt[e];
+                lv[i] = lt[e];
+            }
+        }
+        stage_rows(y, ldy, row0, M, k4n, sY, tid);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = tid + i * HD_THREADS;
+            if (e < HD_ROWS * C) { sG[e] = e < nin ? gv[i] : 0.f; sP[e] = e < nin ? lv[i] : 0.f; }
+        }
+        __syncthreads();
+        {   // dz = g - exp(logp) * sum_j g_j: 4 lanes per row; classes >= C are zero columns
+            const int rr = tid >> 2, part = tid & 3;
+            float gs = 0.f;
+            for (int j = part; j < C; j += 4) gs += sG[rr * C + j];
+            gs += __shfl_xor(gs, 1);
+            gs += __shfl_xor(gs, 2);
+            for (int j = part; j < HD_CMAX; j += 4)
+                sD[rr * HD_LDD + j] = j < C ? sG[rr * C + j] - expf(sP[rr * C + j]) * gs : 0.f;
+        }
+        __syncthreads();
+        if (gy) {
+            const bool full = row0 + HD_ROWS <= M;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                hd_f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float *aRow = &sD[(rb * 32 + l31) * HD_LDD + half * 16];
+                const float *bCol = &sW[(half * 16) * HD_LDW + col];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4 *>(aRow + 4 * q);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bCol[(4 * q + 0) * HD_LDW], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bCol[(4 * q + 1) * HD_LDW], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bCol[(4 * q + 2) * HD_LDW], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bCol[(4 * q + 3) * HD_LDW], acc, 0, 0, 0);
+                }
+                float *o = gy + (size_t)(row0 + rb * 32 + 4 * half) * ldgy + col;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * ldgy] = acc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2);
+                        if (row0 + rb * 32 + 4 * half + rl < M) o[(size_t)rl * ldgy] = acc[r];
+                    }
+                }
+            }
+        }
+        {   // dW block: A[class][row] = dz^T, B[row][col] = y; lane half h reduces rows [32 h, 32 h + 32)
+            const float *dBase = &sD[(half * 32) * HD_LDD + l31];
+            const float *yBase = &sY[(half * 32) * HD_LDY + col];
+#pragma unroll 8
+            for (int t = 0; t < 32; ++t)
+                accW = __builtin_amdgcn_mfma_f32_32x32x2f32(dBase[t * HD_LDD], yBase[t * HD_LDY], accW, 0, 0, 0);
+        }
+        if (tid < HD_CMAX)
+            for (int r = 0; r < HD_ROWS; ++r) dba += sD[r * HD_LDD + tid];
+    }
+    // slab [C][K+1] of this workgroup: C/D layout row (class) = (r & 3) + 8 (r >> 2) + 4 half, column = col
+    float *slab = partial + (size_t)blockIdx.x * C * (K + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cls = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (cls < C) slab[(size_t)cls * (K + 1) + col] = accW[r];
+    }
+    if (tid < C) slab[(size_t)tid * (K + 1) + K] = dba;
+}
+
 // ---- weighted negative log-likelihood ---------------------------------------------------------------------
 // loss = sum_i -w[t_i] * logp[i][t_i] / sum_i w[t_i]   (rows with t_i == ignore_index are skipped,
 // F.nll_loss reduction='mean').  Partials per workgroup in double, combined in order.
@@ -380,8 +491,12 @@ PN2_EXPORT int pn2_head_logits_backward(const float *glogp, const float *logp, c
     if (gy && ((ldgy & 3) || !aligned16(gy))) return PN2_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int P = pn2_head_logits_partials(M);
-    hipLaunchKernelGGL(head_logits_backward_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
-                       partial, M, K, C);
+    if (K == HD_KMAX && pn2::tune_get("hd_mfma", 1))
+        hipLaunchKernelGGL(head_logits_backward_mfma_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
+                           partial, M, C);
+    else
+        hipLaunchKernelGGL(head_logits_backward_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
+                           partial, M, K, C);
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK) return rc;
     return pn2::launch_dw_reduce(partial, P, C, K, dw, db, s);       // same slab layout as the MLP's dW partials

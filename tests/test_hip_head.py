@@ -16,7 +16,7 @@ def env():
     return torch, head
 
 
-@pytest.mark.parametrize("M,K,C", [(4096, 128, 13), (1000, 128, 8), (77, 64, 17), (16 * 4096, 128, 13), (3, 32, 32)])
+@pytest.mark.parametrize("M,K,C", [(4096, 128, 13), (1000, 128, 8), (77, 64, 17), (16 * 4096, 128, 13), (3, 32, 32), (200, 128, 32), (65, 128, 18)])
 def test_head_logits_forward_backward(env, M, K, C):
     torch, head = env
     g = torch.Generator().manual_seed(M + K + C)
