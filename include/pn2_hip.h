@@ -229,6 +229,19 @@ int pn2_head_logits_partials(int M);
 int pn2_head_logits_backward(const float *glogp, const float *logp, const float *y, int ldy, const float *w,
                              float *gy, int ldgy, float *partial, float *dw, float *db, int M, int K, int C,
                              pn2_stream_t stream);
+/* The same two with the dropout of models/pointnet2_sem_seg.py:36 (nn.Dropout(0.5) between relu(bn1(conv1)) and conv2)
+ * applied to y on the fly: an element (row, column) is kept with probability 1 - drop_p (kept values scaled by
+ * 1/(1-drop_p)), the keep-mask being a counter-based hash of (*drop_seed, row, column) that forward and backward
+ * regenerate instead of storing it.  drop_seed: one 64-bit word in device memory, read when the kernel runs (so a
+ * captured graph sees a fresh value per replay); NULL or drop_p == 0: no dropout.  gy is the gradient w.r.t. the
+ * un-dropped y.  pn2_dropout_mask writes that mask ([M][K] bytes, 1 = kept) for tests. */
+int pn2_head_logits_dropout(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K,
+                            int C, const unsigned long long *drop_seed, float drop_p, pn2_stream_t stream);
+int pn2_head_logits_dropout_backward(const float *glogp, const float *logp, const float *y, int ldy, const float *w,
+                                     float *gy, int ldgy, float *partial, float *dw, float *db, int M, int K, int C,
+                                     const unsigned long long *drop_seed, float drop_p, pn2_stream_t stream);
+int pn2_dropout_mask(const unsigned long long *drop_seed, float drop_p, long long M, int K, unsigned char *mask,
+                     pn2_stream_t stream);
 /* F.nll_loss(pred, target, weight=weight)  (reduction 'mean')   models/pointnet2_sem_seg.py:48
  * loss = sum_i -w[t_i] logp[i][t_i] / sum_i w[t_i] over rows with t_i != ignore_index; wsum receives the
  * denominator for the backward.  weight nullable (= ones).  A target outside [0,C): row skipped,

@@ -14,10 +14,35 @@ constexpr int HD_KMAX = 128;       // feature width the kernels are built for
 constexpr int HD_CMAX = 32;        // classes
 constexpr int HD_LDY = HD_KMAX + 4;
 
+// Dropout in front of conv2 (reference models/pointnet2_sem_seg.py:36, nn.Dropout(0.5)): the Bernoulli keep-mask is a
+// counter-based hash of (seed, row, column), regenerated wherever it is needed (forward staging, backward staging
+// and the gy store) instead of being stored; kept values are scaled by 1/(1-p).  seed == nullptr: no dropout.
+struct DropArgs {
+    const unsigned long long *seed;
+    unsigned thresh;              // p * 2^32: an element is dropped when its hash is below
+    float scale;                  // 1 / (1 - p)
+};
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned row, unsigned col, unsigned thresh)
+{
+    unsigned h = ((unsigned)seed ^ (row * 0x9E3779B1u)) + (((unsigned)(seed >> 32)) ^ (col * 0x85EBCA77u));
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h >= thresh;
+}
+__device__ __forceinline__ float4 drop4(float4 v, const DropArgs &d, unsigned long long seed, unsigned row, unsigned col)
+{
+    v.x = drop_keep(seed, row, col + 0, d.thresh) ? v.x * d.scale : 0.f;
+    v.y = drop_keep(seed, row, col + 1, d.thresh) ? v.y * d.scale : 0.f;
+    v.z = drop_keep(seed, row, col + 2, d.thresh) ? v.z * d.scale : 0.f;
+    v.w = drop_keep(seed, row, col + 3, d.thresh) ? v.w * d.scale : 0.f;
+    return v;
+}
+
 // 64 rows x K floats -> LDS tile: the (up to) 8 float4 of a thread are all loaded before the first LDS store,
 // unconditionally (clamped row, masked value): a load-store loop would wait for every load in turn.
-__device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy, int row0, int M, int k4n, float *__restrict__ sY, int tid)
+__device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy, int row0, int M, int k4n, float *__restrict__ sY, int tid,
+                                           const DropArgs &d)
 {
+    const unsigned long long seed = d.seed ? *d.seed : 0ull;
     constexpr int NI = HD_ROWS * (HD_KMAX / 4) / HD_THREADS;          // 8
     const int total = HD_ROWS * k4n;
     float4 v[NI];
@@ -32,7 +57,9 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy,
         const int e = tid + i * HD_THREADS;
         if (e < total) {
             const int r = e / k4n, q = e - r * k4n;
-            *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = row0 + r < M ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o = row0 + r < M ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.seed) o = drop4(o, d, seed, (unsigned)(row0 + r), (unsigned)(4 * q));
+            *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = o;
         }
     }
 }
@@ -44,7 +71,7 @@ template <int CQ>   // classes per thread = ceil(C / 4)
 __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__restrict__ y, int ldy,
                                                                 const float *__restrict__ w,
                                                                 const float *__restrict__ bias,
-                                                                float *__restrict__ logp, int M, int K, int C)
+                                                                float *__restrict__ logp, int M, int K, int C, DropArgs drop)
 {
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
@@ -56,7 +83,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
         const int j = e / k4n, q = e - j * k4n;
         *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
     }
-    stage_rows(y, ldy, row0, M, k4n, sY, tid);
+    stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
     __syncthreads();
     const int r = tid & 63, jq = tid >> 6;
     float acc[CQ];
@@ -115,7 +142,7 @@ constexpr int HD_LDW = HD_KMAX + 4;
 __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const float *__restrict__ y, int ldy,
                                                                      const float *__restrict__ w,
                                                                      const float *__restrict__ bias,
-                                                                     float *__restrict__ logp, int M, int C)
+                                                                     float *__restrict__ logp, int M, int C, DropArgs drop)
 {
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_LDW];
@@ -127,7 +154,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
         const int j = e / k4n, q = e - j * k4n;
         *reinterpret_cast<float4 *>(&sW[j * HD_LDW + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * HD_KMAX + 4 * q]);
     }
-    stage_rows(y, ldy, row0, M, k4n, sY, tid);
+    stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int rb = wave & 1, kh = wave >> 1;
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
 // fixed order by head_dw_reduce_kernel.
 __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     const float *__restrict__ g, const float *__restrict__ logp, const float *__restrict__ y, int ldy,
-    const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int K, int C)
+    const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int K, int C, DropArgs drop)
 {
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
@@ -226,7 +253,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
                 lv[i] = lt[e];
             }
         }
-        stage_rows(y, ldy, row0, M, k4n, sY, tid);
+        stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int e = tid + i * HD_THREADS;
@@ -257,6 +284,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
                     a.z = fmaf(d, b.z, a.z);
                     a.w = fmaf(d, b.w, a.w);
                 }
+                if (drop.seed) a = drop4(a, drop, *drop.seed, (unsigned)(row0 + r), (unsigned)gk4);
                 if (full || row0 + r < M) *reinterpret_cast<float4 *>(&gy[(size_t)(row0 + r) * ldgy + gk4]) = a;
             }
         }
@@ -294,7 +322,7 @@ constexpr int HD_LDD = HD_CMAX + 4;
 
 __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
     const float *__restrict__ g, const float *__restrict__ logp, const float *__restrict__ y, int ldy,
-    const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int C)
+    const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int C, DropArgs drop)
 {
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_LDW];
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
                 lv[i] = lt[e];
             }
         }
-        stage_rows(y, ldy, row0, M, k4n, sY, tid);
+        stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int e = tid + i * HD_THREADS;
@@ -363,6 +391,14 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bCol[(4 * q + 1) * HD_LDW], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bCol[(4 * q + 2) * HD_LDW], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bCol[(4 * q + 3) * HD_LDW], acc, 0, 0, 0);
+                }
+                if (drop.seed) {
+                    const unsigned long long seed = *drop.seed;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned row = (unsigned)(row0 + rb * 32 + 4 * half + (r & 3) + 8 * (r >> 2));
+                        acc[r] = drop_keep(seed, row, (unsigned)col, drop.thresh) ? acc[r] * drop.scale : 0.f;
+                    }
                 }
                 float *o = gy + (size_t)(row0 + rb * 32 + 4 * half) * ldgy + col;
                 if (full) {
@@ -451,24 +487,63 @@ __global__ __launch_bounds__(256) void nll_backward_kernel(const float *__restri
     glogp[e] = v;
 }
 
+__global__ __launch_bounds__(256) void dropout_mask_kernel(DropArgs d, long long M, int K, unsigned char *__restrict__ mask)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * K) return;
+    const long long r = e / K;
+    mask[e] = drop_keep(*d.seed, (unsigned)r, (unsigned)(e - r * K), d.thresh) ? 1 : 0;
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+DropArgs make_drop(const unsigned long long *seed, float p)
+{
+    DropArgs d;
+    d.seed = (seed && p > 0.f) ? seed : nullptr;
+    const double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    d.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    return d;
+}
 
 }  // namespace
 
 PN2_EXPORT int pn2_head_logits(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K,
                                int C, pn2_stream_t stream)
 {
+    return pn2_head_logits_dropout(y, ldy, w, bias, logp, M, K, C, nullptr, 0.f, stream);
+}
+
+PN2_EXPORT int pn2_dropout_mask(const unsigned long long *seed, float p, long long M, int K, unsigned char *mask,
+                                pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(seed); PN2_REQUIRE_PTR(mask);
+    if (M <= 0 || K <= 0 || p < 0.f || p > 1.f) return PN2_ERR_SHAPE;
+    DropArgs d = make_drop(seed, p);
+    d.seed = seed;
+    const long long n = M * K;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, M, K, mask);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_head_logits_dropout(const float *y, int ldy, const float *w, const float *bias, float *logp, int M,
+                                       int K, int C, const unsigned long long *drop_seed, float drop_p,
+                                       pn2_stream_t stream)
+{
+    if (drop_p < 0.f || drop_p > 1.f) return PN2_ERR_SHAPE;
+    const DropArgs drop = make_drop(drop_seed, drop_p);
     PN2_REQUIRE_PTR(y); PN2_REQUIRE_PTR(w); PN2_REQUIRE_PTR(logp);
     if (M <= 0 || K <= 0 || C <= 0 || ldy < K) return PN2_ERR_SHAPE;
     if (K > HD_KMAX || C > HD_CMAX || (K & 3) || (ldy & 3) || !aligned16(y) || !aligned16(w)) return PN2_ERR_UNSUPPORTED;
     const dim3 grid((M + HD_ROWS - 1) / HD_ROWS);
     hipStream_t s = (hipStream_t)stream;
     if (K == HD_KMAX && pn2::tune_get("hd_mfma", 1)) {
-        hipLaunchKernelGGL(head_logits_mfma_kernel, grid, dim3(HD_THREADS), 0, s, y, ldy, w, bias, logp, M, C);
+        hipLaunchKernelGGL(head_logits_mfma_kernel, grid, dim3(HD_THREADS), 0, s, y, ldy, w, bias, logp, M, C, drop);
         return PN2_LAUNCH_RC();
     }
     const int cq = (C + 3) / 4;
-#define PN2_HD(Q) hipLaunchKernelGGL((head_logits_kernel<Q>), grid, dim3(HD_THREADS), 0, s, y, ldy, w, bias, logp, M, K, C)
+#define PN2_HD(Q) hipLaunchKernelGGL((head_logits_kernel<Q>), grid, dim3(HD_THREADS), 0, s, y, ldy, w, bias, logp, M, K, C, drop)
     if (cq <= 2) PN2_HD(2); else if (cq <= 4) PN2_HD(4); else PN2_HD(8);
 #undef PN2_HD
     return PN2_LAUNCH_RC();
@@ -484,6 +559,16 @@ PN2_EXPORT int pn2_head_logits_backward(const float *glogp, const float *logp, c
                                         float *gy, int ldgy, float *partial, float *dw, float *db, int M, int K, int C,
                                         pn2_stream_t stream)
 {
+    return pn2_head_logits_dropout_backward(glogp, logp, y, ldy, w, gy, ldgy, partial, dw, db, M, K, C, nullptr, 0.f, stream);
+}
+
+PN2_EXPORT int pn2_head_logits_dropout_backward(const float *glogp, const float *logp, const float *y, int ldy,
+                                                const float *w, float *gy, int ldgy, float *partial, float *dw, float *db,
+                                                int M, int K, int C, const unsigned long long *drop_seed, float drop_p,
+                                                pn2_stream_t stream)
+{
+    if (drop_p < 0.f || drop_p > 1.f) return PN2_ERR_SHAPE;
+    const DropArgs drop = make_drop(drop_seed, drop_p);
     PN2_REQUIRE_PTR(glogp); PN2_REQUIRE_PTR(logp); PN2_REQUIRE_PTR(y); PN2_REQUIRE_PTR(w);
     PN2_REQUIRE_PTR(partial); PN2_REQUIRE_PTR(dw);
     if (M <= 0 || K <= 0 || C <= 0 || ldy < K || (gy && ldgy < K)) return PN2_ERR_SHAPE;
@@ -493,10 +578,10 @@ PN2_EXPORT int pn2_head_logits_backward(const float *glogp, const float *logp, c
     const int P = pn2_head_logits_partials(M);
     if (K == HD_KMAX && pn2::tune_get("hd_mfma", 1))
         hipLaunchKernelGGL(head_logits_backward_mfma_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
-                           partial, M, C);
+                           partial, M, C, drop);
     else
         hipLaunchKernelGGL(head_logits_backward_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
-                           partial, M, K, C);
+                           partial, M, K, C, drop);
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK) return rc;
     return pn2::launch_dw_reduce(partial, P, C, K, dw, db, s);       // same slab layout as the MLP's dW partials

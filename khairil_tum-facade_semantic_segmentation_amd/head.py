@@ -15,7 +15,7 @@ IGNORE_INDEX = -100          # F.nll_loss default, which the reference does not 
 
 class _HeadLogits(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, w, b):
+    def forward(ctx, y, w, b, drop_p, seed):
         dev = _dev(y, w, b)
         lib = _lib.load()
         M, K = y.shape
@@ -23,9 +23,11 @@ class _HeadLogits(torch.autograd.Function):
         w2 = w.reshape(C, K).contiguous()
         logp = torch.empty((M, C), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.pn2_head_logits(_ptr(y), y.stride(0), _ptr(w2), _ptr(b), _ptr(logp), M, K, C, _stream(dev))
-        _lib.check(rc, "pn2_head_logits")
+            rc = lib.pn2_head_logits_dropout(_ptr(y), y.stride(0), _ptr(w2), _ptr(b), _ptr(logp), M, K, C, _ptr(seed),
+                                             float(drop_p), _stream(dev))
+        _lib.check(rc, "pn2_head_logits_dropout")
         ctx.save_for_backward(y, w2, logp)
+        ctx.drop_p, ctx.seed = float(drop_p), seed
         ctx.wshape = w.shape
         ctx.has_bias = b is not None
         return logp
@@ -45,20 +47,38 @@ class _HeadLogits(torch.autograd.Function):
         dw = torch.empty((C, K), **f32)
         db = torch.empty(C, **f32) if ctx.has_bias else None
         with torch.cuda.device(dev):
-            rc = lib.pn2_head_logits_backward(_ptr(g), _ptr(logp), _ptr(y), y.stride(0), _ptr(w2), _ptr(gy),
-                                              0 if gy is None else gy.stride(0), _ptr(part), _ptr(dw), _ptr(db), M, K, C,
-                                              _stream(dev))
-        _lib.check(rc, "pn2_head_logits_backward")
-        return gy, dw.view(ctx.wshape), db
+            rc = lib.pn2_head_logits_dropout_backward(_ptr(g), _ptr(logp), _ptr(y), y.stride(0), _ptr(w2), _ptr(gy),
+                                                      0 if gy is None else gy.stride(0), _ptr(part), _ptr(dw), _ptr(db),
+                                                      M, K, C, _ptr(ctx.seed), ctx.drop_p, _stream(dev))
+        _lib.check(rc, "pn2_head_logits_dropout_backward")
+        return gy, dw.view(ctx.wshape), db, None, None
 
 
-def head_logits(y, weight, bias):
-    """y [M,K] rows, weight [C,K] or [C,K,1] (a 1x1 Conv1d's), bias [C] or None -> log-probs [M,C]."""
-    _dev(y, weight, bias)
+def head_logits(y, weight, bias, drop_p=0.0, seed=None):
+    """y [M,K] rows, weight [C,K] or [C,K,1] (a 1x1 Conv1d's), bias [C] or None -> log-probs [M,C].
+    drop_p > 0: the reference's nn.Dropout(drop_p) in front of conv2 (models/pointnet2_sem_seg.py:36) applied on the fly;
+    seed = a one-element int64 tensor on the device (drawn here from torch's generator when omitted), from which
+    forward and backward regenerate the keep-mask."""
+    dev = _dev(y, weight, bias)
     y = y.to(torch.float32)
     if y.stride(-1) != 1:
         y = y.contiguous()
-    return _HeadLogits.apply(y, weight, bias)
+    if drop_p > 0.0 and seed is None:
+        seed = torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.int64, device=dev)
+    if drop_p <= 0.0:
+        seed = None
+    return _HeadLogits.apply(y, weight, bias, float(drop_p), seed)
+
+
+def dropout_mask(seed, drop_p, M, K):
+    """The keep-mask head_logits(..., drop_p, seed) applies to y [M,K] (bool tensor); for tests."""
+    dev = seed.device
+    lib = _lib.load()
+    mask = torch.empty((M, K), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_dropout_mask(_ptr(seed), float(drop_p), M, K, _ptr(mask), _stream(dev))
+    _lib.check(rc, "pn2_dropout_mask")
+    return mask.bool()
 
 
 class _NLL(torch.autograd.Function):

@@ -14,6 +14,8 @@ from . import pointnet2_utils as _utils
 from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction
 
 _INVERT_GROUPING = os.environ.get("PN2_INVERT_GROUPING", "0") == "1"
+# the head's dropout inside the conv2 kernels (PN2_FUSED_DROPOUT=0: torch's F.dropout in front of them, for A/B runs)
+_FUSED_DROPOUT = os.environ.get("PN2_FUSED_DROPOUT", "1") == "1"
 
 # (npoint, radius, nsample, mlp) per set-abstraction level; reference :9-12
 SA_LEVELS = ((1024, 0.1, 32, (32, 32, 64)), (256, 0.2, 32, (64, 64, 128)),
@@ -89,8 +91,12 @@ class get_model(nn.Module):
             return h.permute(0, 2, 1), feat[4].permute(0, 2, 1)
         B, N, C = up.shape
         h = _utils._mlp(up.reshape(B * N, C), None, [self.conv1], [self.bn1])   # conv1 -> bn1 -> relu (:36)
-        h = self.drop1(h)
-        logp = head.head_logits(h, self.conv2.weight, self.conv2.bias)         # conv2 -> log_softmax (:37-38)
+        # dropout (:36) inside the head kernels: the keep-mask is regenerated from a device seed, never stored
+        p = float(self.drop1.p) if self.training else 0.0
+        if p > 0.0 and _FUSED_DROPOUT:
+            logp = head.head_logits(h, self.conv2.weight, self.conv2.bias, drop_p=p)
+        else:
+            logp = head.head_logits(self.drop1(h), self.conv2.weight, self.conv2.bias)     # conv2 -> log_softmax (:37-38)
         return logp.view(B, N, -1), feat[4].permute(0, 2, 1)
 
 

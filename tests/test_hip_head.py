@@ -89,3 +89,33 @@ def test_head_rejects_cpu_tensors(env):
         head.head_logits(torch.randn(8, 128), torch.randn(13, 128), None)
     with pytest.raises(RuntimeError):
         head.nll_loss(torch.randn(8, 13), torch.zeros(8, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("M,K,C,p", [(4096, 128, 13, 0.5), (1000, 128, 8, 0.3), (77, 64, 17, 0.5), (65, 128, 18, 0.9)])
+def test_head_logits_fused_dropout(env, M, K, C, p):
+    """Dropout in front of conv2 applied inside the kernels: forward and backward must use the SAME keep-mask (the one
+    pn2_dropout_mask reports for the seed), i.e. equal torch ops on y * mask / (1 - p)."""
+    torch, head = env
+    g = torch.Generator().manual_seed(M + K + C)
+    y = torch.randn(M, K, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(C, K, 1, generator=g) * 0.2).cuda().requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_(True)
+    seed = torch.tensor([0x1234567 + M], dtype=torch.int64, device="cuda")
+    mask = head.dropout_mask(seed, p, M, K)
+    rate = float(mask.float().mean())
+    assert abs(rate - (1.0 - p)) < 4.0 * (p * (1 - p) / (M * K)) ** 0.5 + 1e-3, rate
+    other = head.dropout_mask(seed + 1, p, M, K)
+    assert float((mask != other).float().mean()) > 0.5 * 2 * p * (1 - p)
+
+    out = head.head_logits(y, w, b, drop_p=p, seed=seed)
+    yr, wr, br = (t.detach().clone().requires_grad_(True) for t in (y, w, b))
+    ref = torch.log_softmax((yr * mask / (1.0 - p)) @ wr.reshape(C, K).t() + br, dim=1)
+    assert float((out - ref).detach().abs().max()) <= 2e-5 * (float(ref.detach().abs().max()) + 1.0)
+    go = torch.randn(M, C, generator=g).cuda()
+    out.backward(go)
+    ref.backward(go)
+    for a, r, what in ((y.grad, yr.grad, "gy"), (w.grad, wr.grad, "dw"), (b.grad, br.grad, "db")):
+        s = float(r.abs().max()) + 1e-6
+        assert float((a - r).abs().max()) <= 2e-4 * s + 1e-6, what
+    # a dropped element receives no gradient
+    assert float(y.grad[~mask].abs().max() if (~mask).any() else 0.0) == 0.0
