@@ -16,6 +16,8 @@ from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction
 _INVERT_GROUPING = os.environ.get("PN2_INVERT_GROUPING", "0") == "1"
 # the head's dropout inside the conv2 kernels (PN2_FUSED_DROPOUT=0: torch's F.dropout in front of them, for A/B runs)
 _FUSED_DROPOUT = os.environ.get("PN2_FUSED_DROPOUT", "1") == "1"
+# gradients of a level's features (grouping of the next level + skip connection) summed inside the grouping backward
+_SKIP_IN_SCATTER = os.environ.get("PN2_SKIP_IN_SCATTER", "1") == "1"
 
 # (npoint, radius, nsample, mlp) per set-abstraction level; reference :9-12
 SA_LEVELS = ((1024, 0.1, 32, (32, 32, 64)), (256, 0.2, 32, (64, 64, 128)),
@@ -77,7 +79,12 @@ class get_model(nn.Module):
         feat = [pts]
         for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
             pre = None if geometry is None else (geometry[2 * i], geometry[2 * i + 1]) + self._inverse(geometry, i)
-            g, f = sa.forward_cl(geo[-1], feat[-1], geometry=pre)
+            if i > 0 and pre is not None and _SKIP_IN_SCATTER:
+                # feat[i] feeds this level's grouping AND a feature-propagation skip: route the skip through the grouping
+                # op's second output, so that both gradients meet inside its scatter (no zero fill, no add kernel)
+                g, f, feat[-1] = sa.forward_cl(geo[-1], feat[-1], geometry=pre, skip=True)
+            else:
+                g, f = sa.forward_cl(geo[-1], feat[-1], geometry=pre)
             geo.append(g)
             feat.append(f)
         up = feat[4]

@@ -149,20 +149,28 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
         _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, self.npoint, start)
         return new_xyz, ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
 
-    def forward_cl(self, xyz, points, start=None, geometry=None):
+    def forward_cl(self, xyz, points, start=None, geometry=None, skip=False):
         """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C'].
-        `geometry` = a precomputed (new_xyz, idx[, inverse index]) tuple from geometry()."""
+        `geometry` = a precomputed (new_xyz, idx[, inverse index]) tuple from geometry().
+        skip (with `geometry`): a third result, `points` again for the caller's skip connection (ops.group_points
+        with_skip: the two gradients of the points are then summed inside the grouping backward)."""
+        alias = points
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz, points)
         elif geometry is not None:
             new_xyz, idx = geometry[0], geometry[1]
             inv = geometry[2] if len(geometry) > 2 else None       # ops.invert_index(idx, N): atomic-free backward
-            grouped = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv)
+            if skip and points is not None:
+                grouped, alias = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv, with_skip=True)
+            else:
+                grouped = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start,
                                                 pad_to=4)
         B, S, K, C = grouped.shape
         y = _mlp(grouped.reshape(B * S * K, C), None, self.mlp_convs, self.mlp_bns, pool_k=K)   # :196-200
+        if skip:
+            return new_xyz, y.reshape(B, S, -1), alias
         return new_xyz, y.reshape(B, S, -1)
 
     def forward(self, xyz, points):

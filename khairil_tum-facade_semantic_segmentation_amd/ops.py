@@ -211,9 +211,11 @@ def _gather_sum(src, rows_src, col0, inv, weight, ediv, nkeys, D):
     return out
 
 
-def index_points_backward(grad_out, idx, N, D, col0=0, inv=None):
+def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None):
     """grad_points[B,N,D] = scatter-add of grad_out[B,...,Cg][..., col0:col0+D] at idx; with
-    inv = invert_index(idx, N) the same sum as an atomic-free gather in a fixed order."""
+    inv = invert_index(idx, N) the same sum as an atomic-free gather in a fixed order.
+    into = a contiguous fp32 [B,N,D] tensor that already holds another gradient of the same points: the scatter then
+    accumulates onto it in place (no zero fill, no add afterwards) and returns it."""
     dev = _dev(grad_out, idx)
     lib = _lib.load()
     grad_out, idx = _f32c(grad_out), _i64c(idx)
@@ -221,8 +223,14 @@ def index_points_backward(grad_out, idx, N, D, col0=0, inv=None):
     M = idx.numel() // max(B, 1)
     Cg = grad_out.shape[-1]
     if inv is not None:
-        return _gather_sum(grad_out, M, col0, inv, None, 1, N, D)
-    gp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
+        out = _gather_sum(grad_out, M, col0, inv, None, 1, N, D)
+        return out if into is None else out + into
+    if into is not None and into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == (B, N, D):
+        gp = into
+    else:
+        gp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
+        if into is not None:
+            gp += into
     with torch.cuda.device(dev):
         rc = lib.pn2_index_points_backward(_ptr(grad_out), _ptr(idx), B, N, D, M, Cg, col0, _ptr(gp), _stream(dev))
     _lib.check(rc, "pn2_index_points_backward")
@@ -262,7 +270,7 @@ def index_points(points, idx):
 
 class _GroupPoints(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, idx, pad_to, inv_off=None, inv_ent=None):
+    def forward(ctx, xyz, new_xyz, points, idx, pad_to, inv_off=None, inv_ent=None, with_skip=False):
         dev = _dev(xyz, new_xyz, points, idx)
         lib = _lib.load()
         B, N, _ = xyz.shape
@@ -277,27 +285,38 @@ class _GroupPoints(torch.autograd.Function):
         ctx.has_inv = inv_off is not None
         ctx.save_for_backward(idx, *((inv_off, inv_ent) if ctx.has_inv else ()))
         ctx.shape = (N, D)
+        ctx.with_skip = bool(with_skip)
+        if with_skip:
+            # second output: the points themselves, for the caller's OTHER use of them (the skip connection into
+            # feature propagation) -- its gradient then arrives here and the scatter accumulates onto it
+            return out, points.view_as(points)
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, gskip=None):
         idx = ctx.saved_tensors[0]
         inv = ctx.saved_tensors[1:3] if ctx.has_inv else None
         N, D = ctx.shape
         if D == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None, None, None, None
-        return None, None, index_points_backward(gout, idx, N, D, col0=3, inv=inv), None, None, None, None
+            return None, None, None, None, None, None, None, None
+        if gout is None:
+            return None, None, gskip, None, None, None, None, None
+        return None, None, index_points_backward(gout, idx, N, D, col0=3, inv=inv, into=gskip), None, None, None, None, None
 
 
-def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None):
+def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None, with_skip=False):
     """[xyz[idx]-new_xyz, points[idx]] for a given idx (models/pointnet2_utils.py:127-132).
-    inv = invert_index(idx, N): the backward then gathers instead of scatter-adding."""
+    inv = invert_index(idx, N): the backward then gathers instead of scatter-adding.
+    with_skip: also returns `points` again (same storage); a caller that uses the points a second time (skip connection)
+    through THAT tensor gets both gradients summed inside the scatter instead of by a zero fill + add."""
     dev = _dev(xyz, new_xyz, points, idx)
     if points is not None:
         points = points.to(torch.float32).contiguous()
     io, ie = inv if inv is not None else (None, None)
-    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to, io, ie)
+    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to, io, ie, bool(with_skip and points is not None))
     _after_fault_op(dev, "group_points")
+    if with_skip and points is None:
+        return out, None
     return out
 
 

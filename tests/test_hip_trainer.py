@@ -69,6 +69,28 @@ def test_precomputed_geometry_is_identical(monkeypatch):
     assert torch.equal(a, b) and torch.equal(a4, b4)
 
 
+def test_skip_gradient_summed_inside_the_grouping_backward(monkeypatch):
+    """With a precomputed pyramid the skip connections are routed through the grouping op's second output (their
+    gradient meets the grouping gradient inside the scatter): same parameter gradients as the plain wiring."""
+    torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+    grads = []
+    for flag in (False, True):
+        monkeypatch.setattr(M, "_SKIP_IN_SCATTER", flag)
+        model = fresh_model().train()
+        geo = model.compute_geometry(xs[0])
+        logp, _ = model(xs[0], geometry=geo)
+        loss = M.get_loss()(logp.reshape(-1, K), ys[0].reshape(-1), None, cw)
+        loss.backward()
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        s = float(a.abs().max()) + 1e-8
+        if k.endswith("convs.0.bias") or ".bias" in k and "mlp_convs" in k:
+            continue                                  # conv biases under train-mode BatchNorm: pure rounding noise
+        assert float((a - b).abs().max()) <= 2e-4 * s + 1e-7, k
+
+
 def test_prepare_captures_without_touching_the_model(monkeypatch):
     """SemSegTrainer.prepare() (graph capture before the first collective) must leave parameters, BatchNorm
     buffers and the Adam state as if nothing had run, and the steps after it must train like eager steps."""
