@@ -17,6 +17,11 @@ SIGNATURES = {
     "pn2_farthest_point_sample": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_square_distance": [_vp, _vp, _ci, _ci, _ci, _vp, _vp],
     "pn2_ball_query_group": [_cd, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp],
+    "pn2_farthest_point_sample_plan": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _cd, _ci, _vp, _vp, _vp],
+    "pn2_ball_plan_bytes": [_ci, _ci, _ci],
+    "pn2_ball_pack_rows": [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
+    "pn2_ball_plan": [_cd, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
+    "pn2_ball_query_group_planned": [_cd, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp],
     "pn2_index_points": [_vp, _vp, _ci, _ci, _ci, _cl, _vp, _vp, _vp],
     "pn2_index_points_backward": [_vp, _vp, _ci, _ci, _ci, _cl, _ci, _ci, _vp, _vp],
     "pn2_group_points": [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp],
@@ -82,7 +87,7 @@ def load():
         except AttributeError:
             raise Pn2LibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.argtypes = args
-        fn.restype = ctypes.c_char_p if name == "pn2_error_string" else _ci
+        fn.restype = ctypes.c_char_p if name == "pn2_error_string" else (ctypes.c_longlong if name == "pn2_ball_plan_bytes" else _ci)
     _lib = lib
     return lib
 

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     const int s_base = tile * GR_CENT;
     const float *bx = xyz + (size_t)b * N * 3;
     const float *bc = new_xyz + (size_t)b * S * 3;
+    PN2_STAMP(0);
 
     // ---- (1) this thread's 4 points (12 consecutive floats when the block is 16-byte aligned) ---------
     float px[GR_PT], py[GR_PT], pz[GR_PT];
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     const int scl = s_ok ? my_s : S - 1;
     const float cx = bc[scl * 3 + 0], cy = bc[scl * 3 + 1], cz = bc[scl * 3 + 2];
     const float cn = pn2::norm3(cx, cy, cz);
+    PN2_STAMP(1);
 
     for (int i = tid; i < GR_MAXCELLS + 4; i += GR_THREADS) start[i] = 0;
     {
@@ -132,7 +134,9 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         for (int k = 1; k < 8; ++k) v = lane == k ? q[k] : v;
         red[wave * 8 + lane] = v;
     }
+    PN2_STAMP(2);
     __syncthreads();
+    PN2_STAMP(3);
     {
         // lane -> (wave lane & 15, quantity lane >> 4 and 4 + lane >> 4); 16-lane row maxima, then one lane per row
         const float va = row_max_f(red[(lane & 15) * 8 + (lane >> 4)]);
@@ -177,7 +181,9 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
             prank[i] = atomicAdd(&start[pcell[i]], 1u);
         }
     }
+    PN2_STAMP(4);
     __syncthreads();
+    PN2_STAMP(5);
     // ---- (4) exclusive scan of the cell counts (4 cells per thread) -------------------------------
     {
         const int c0 = tid * 4;
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         if (tid == 0) start[GR_MAXCELLS] = (unsigned)N;
     }
     __syncthreads();
+    PN2_STAMP(6);
     // ---- (5) scatter into cell order (cells past the grid are empty, their start is N) ---------------
 #pragma unroll
     for (int i = 0; i < GR_PT; ++i) {
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         }
     }
     __syncthreads();
+    PN2_STAMP(7);
 
     if (dbg == 1) return;
     // From here on a centroid's 16 lanes depend on nothing but their own bitmap row, so there is no
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     }
     // LDS operations of one wave complete in order; the fence keeps the compiler from moving the reads up
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    PN2_STAMP(8);
     if (dbg == 2) return;
     // ---- (7) the K lowest set bits, in order: lane l16 owns words 8*l16 .. 8*l16+7 ----------------------
     unsigned short *oi = mIdx + cl * K;
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         n = min(total, K);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    PN2_STAMP(9);
     if (dbg == 3) return;
     // ---- (8) idx [b, s, 0..K) (padded with the first member, :104-106) -------------------------------
     {
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         for (int k = l16; k < K; k += 16) orow[k] = n > 0 ? (int64_t)oi[k < n ? k : 0] : (int64_t)N;   // empty: IndexError at :59
         if (n == 0 && l16 == 0 && err_count) atomicAdd(err_count, 1);
     }
+    PN2_STAMP(10);
     if (!grouped) return;
     // ---- (9) grouped rows [xyz - centroid, feats] of this centroid: K rows of qpr float4, contiguous;
     //      lane l16 writes float4 number l16 + 16 i ------------------------------------------------------
@@ -338,6 +349,9 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
             }
         }
     }
+    PN2_STAMP(11);
+    PN2_STAMP_DRAIN();                   // lab builds only: stamps 11 -> 12 = drain of the row stores
+    PN2_STAMP(12);
 }
 
 size_t gr_lds_bytes(int K)

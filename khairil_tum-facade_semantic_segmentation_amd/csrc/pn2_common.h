@@ -14,6 +14,13 @@
     do { if ((p) == nullptr) return PN2_ERR_NULL; } while (0)
 #define PN2_LAUNCH_RC() ((int)hipGetLastError())
 
+// Phase stamps for the lab programs under tools/ (which define PN2_STAMP before including a kernel source);
+// nothing in the library build.
+#ifndef PN2_STAMP
+#define PN2_STAMP(i) do { } while (0)
+#define PN2_STAMP_DRAIN() do { } while (0)
+#endif
+
 namespace pn2 {
 
 // Developer tuning knob: PN2_TUNE_<NAME>=<int> in the environment overrides a launch heuristic

@@ -78,8 +78,15 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, star
     rounds the last dimension up with zero columns."""
     if start is None:
         start = _next_start(xyz.device)
-    fps_idx, new_xyz = ops.farthest_point_sample_with_xyz(xyz, npoint, start)
-    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to)
+    B, N, _ = xyz.shape
+    D = 0 if points is None else points.shape[2]
+    if xyz.is_cuda and ops.plan_supported(B, N, npoint) and nsample <= 64:
+        # the FPS kernel leaves the ball query's plan of each block (cell-sorted points, per-centroid runs)
+        fps_idx, new_xyz, plan = ops.farthest_point_sample_plan(xyz, npoint, radius, D, start)
+    else:
+        fps_idx, new_xyz = ops.farthest_point_sample_with_xyz(xyz, npoint, start)
+        plan = None
+    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to, plan=plan)
     if returnfps:
         grouped_xyz = ops.index_points(xyz, idx)
         return new_xyz, new_points, grouped_xyz, fps_idx
@@ -146,6 +153,10 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
         ball-query indices.  xyz [B,N,3] -> (new_xyz [B,S,3], idx [B,S,K])."""
         if start is None:
             start = _next_start(xyz.device)
+        B, N, _ = xyz.shape
+        if xyz.is_cuda and ops.plan_supported(B, N, self.npoint) and self.nsample <= 64:
+            _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, self.npoint, self.radius, 0, start)
+            return new_xyz, ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz, plan=plan)
         _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, self.npoint, start)
         return new_xyz, ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
 

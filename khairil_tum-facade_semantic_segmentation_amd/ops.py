@@ -107,6 +107,83 @@ def farthest_point_sample(xyz, npoint, start=None):
     return farthest_point_sample_with_xyz(xyz, npoint, start)[0]
 
 
+class BallPlan:
+    """Per-block query plans of the binned ball query (csrc/pn2_ball_bin.h): cell-sorted points, per-centroid
+    candidate runs and, once pack_rows() has run, the packed rows the grouping gathers from.  Built by
+    farthest_point_sample_plan() (tail of the FPS kernel) or ball_plan() (stand-alone kernel); valid for one
+    (xyz, new_xyz, radius) triple."""
+
+    def __init__(self, buf, B, N, S, D, radius):
+        self.buf, self.B, self.N, self.S, self.D, self.radius = buf, B, N, S, D, float(radius)
+        self.rows_packed = False
+
+    def matches(self, B, N, S, D, radius):
+        return (self.B, self.N, self.S, self.D) == (B, N, S, D) and self.radius == float(radius)
+
+    def pack_rows(self, xyz, points):
+        if self.rows_packed:
+            return
+        lib = _lib.load()
+        dev = self.buf.device
+        with torch.cuda.device(dev):
+            rc = lib.pn2_ball_pack_rows(_ptr(xyz), _ptr(points), self.B, self.N, self.S, self.D, _ptr(self.buf), _stream(dev))
+        _lib.check(rc, "pn2_ball_pack_rows")
+        self.rows_packed = True
+
+
+def plan_supported(B, N, S):
+    """Shapes the planned ball query is built for: many centroids over blocks of a few thousand points."""
+    return B * S >= 4096 and 1024 < N <= 8192
+
+
+def _plan_buffer(B, N, S, D, dev):
+    nbytes = _lib.load().pn2_ball_plan_bytes(N, S, D)
+    if nbytes <= 0:
+        raise RuntimeError("pn2_ball_plan_bytes(%d, %d, %d): unsupported shape" % (N, S, D))
+    return torch.empty((B, nbytes), dtype=torch.uint8, device=dev)       # torch allocations are >= 256-byte aligned
+
+
+def farthest_point_sample_plan(xyz, npoint, radius, D, start=None):
+    """farthest_point_sample_with_xyz whose kernel also leaves the ball-query plan of every block for `radius`
+    (D = feature width of the rows that will be grouped).  -> (idx, new_xyz, BallPlan)."""
+    dev = _dev(xyz, start)
+    lib = _lib.load()
+    xyz = _f32c(xyz)
+    B, N, C = xyz.shape
+    if C != 3:
+        raise ValueError("xyz must be [B,N,3]")
+    if start is None:
+        start = torch.randint(0, N, (B,), dtype=torch.long, device=dev)
+    start = _i64c(start)
+    if start.shape != (B,):
+        raise ValueError("start must be [B]")
+    idx = torch.empty((B, npoint), dtype=torch.int64, device=dev)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=dev)
+    buf = _plan_buffer(B, N, npoint, D, dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_farthest_point_sample_plan(_ptr(xyz), B, N, npoint, _ptr(start), _ptr(idx), _ptr(new_xyz), float(radius),
+                                                int(D), _ptr(buf), _ptr(_err_word(dev)), _stream(dev))
+    _lib.check(rc, "pn2_farthest_point_sample_plan")
+    _after_fault_op(dev, "farthest_point_sample")
+    return idx, new_xyz, BallPlan(buf, B, N, npoint, D, radius)
+
+
+def ball_plan(radius, xyz, new_xyz, points=None):
+    """Stand-alone plan (cell sort + per-centroid runs + packed rows) for query_ball_point / ball_query_group."""
+    dev = _dev(xyz, new_xyz, points)
+    lib = _lib.load()
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    D = 0 if points is None else points.shape[2]
+    buf = _plan_buffer(B, N, S, D, dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_ball_plan(float(radius), _ptr(xyz), _ptr(new_xyz), _ptr(points), B, N, S, D, _ptr(buf), _stream(dev))
+    _lib.check(rc, "pn2_ball_plan")
+    plan = BallPlan(buf, B, N, S, D, radius)
+    plan.rows_packed = True
+    return plan
+
+
 def square_distance(src, dst):
     dev = _dev(src, dst)
     lib = _lib.load()
@@ -125,7 +202,7 @@ def _padded(width, pad_to):
     return (width + pad_to - 1) // pad_to * pad_to
 
 
-def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, pad_to=1):
+def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, pad_to=1, plan=None):
     dev = _dev(xyz, new_xyz, points)
     lib = _lib.load()
     B, N, _ = xyz.shape
@@ -134,16 +211,29 @@ def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, p
     ldg = _padded(3 + D, pad_to)
     idx = torch.empty((B, S, nsample), dtype=torch.int64, device=dev)
     grouped = torch.empty((B, S, nsample, ldg), dtype=torch.float32, device=dev) if want_grouped else None
-    with torch.cuda.device(dev):
-        rc = lib.pn2_ball_query_group(float(radius), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(points), B, N, S,
-                                      D, _ptr(idx), _ptr(grouped), ldg, _ptr(_err_word(dev)), _stream(dev))
-    _lib.check(rc, "pn2_ball_query_group")
+    if plan is not None and not (plan.matches(B, N, S, plan.D, radius) and (plan.D == D or not want_grouped)):
+        plan = None
+    if plan is None and plan_supported(B, N, S) and nsample <= 64:
+        plan = ball_plan(radius, xyz, new_xyz, points if want_grouped else None)
+    if plan is not None:
+        if want_grouped and ldg == 3 + D and (3 + D) % 4 == 0:
+            plan.pack_rows(xyz, points)                       # the fused row stores gather from the plan's packed rows
+        with torch.cuda.device(dev):
+            rc = lib.pn2_ball_query_group_planned(float(radius), int(nsample), _ptr(plan.buf), _ptr(xyz), _ptr(new_xyz),
+                                                  _ptr(points), B, N, S, plan.D, _ptr(idx), _ptr(grouped), ldg,
+                                                  _ptr(_err_word(dev)), _stream(dev))
+        _lib.check(rc, "pn2_ball_query_group_planned")
+    else:
+        with torch.cuda.device(dev):
+            rc = lib.pn2_ball_query_group(float(radius), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(points), B, N, S,
+                                          D, _ptr(idx), _ptr(grouped), ldg, _ptr(_err_word(dev)), _stream(dev))
+        _lib.check(rc, "pn2_ball_query_group")
     _after_fault_op(dev, "query_ball_point")
     return idx, grouped
 
 
-def query_ball_point(radius, nsample, xyz, new_xyz):
-    idx, _ = _ball_query_group_raw(radius, nsample, _f32c(xyz), _f32c(new_xyz), None, False)
+def query_ball_point(radius, nsample, xyz, new_xyz, plan=None):
+    idx, _ = _ball_query_group_raw(radius, nsample, _f32c(xyz), _f32c(new_xyz), None, False, plan=plan)
     return idx
 
 
@@ -153,8 +243,8 @@ class _BallQueryGroup(torch.autograd.Function):
     (SURVEY.md 3.3)."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, radius, nsample, pad_to):
-        idx, grouped = _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, True, pad_to)
+    def forward(ctx, xyz, new_xyz, points, radius, nsample, pad_to, plan=None):
+        idx, grouped = _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, True, pad_to, plan=plan)
         ctx.save_for_backward(idx)
         ctx.shape = (xyz.shape[0], xyz.shape[1], 0 if points is None else points.shape[2])
         ctx.mark_non_differentiable(idx)
@@ -165,18 +255,19 @@ class _BallQueryGroup(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, D = ctx.shape
         if D == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None, None, None
-        return None, None, index_points_backward(ggrouped, idx, N, D, col0=3), None, None, None
+            return None, None, None, None, None, None, None
+        return None, None, index_points_backward(ggrouped, idx, N, D, col0=3), None, None, None, None
 
 
-def ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to=1):
+def ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to=1, plan=None):
     """Fused query_ball_point + grouping: (idx [B,S,K] int64, grouped [B,S,K,3+D]).  pad_to = 4
     rounds the row width up to a multiple of 4 floats (extra columns are zero) so that the MLP
-    kernels can use 16-byte loads on widths like 67 / 131 / 259."""
+    kernels can use 16-byte loads on widths like 67 / 131 / 259.  plan = the BallPlan that
+    farthest_point_sample_plan() left for these (xyz, new_xyz, radius)."""
     xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
     if points is not None:
         points = points.to(torch.float32).contiguous()
-    return _BallQueryGroup.apply(xyz, new_xyz, points, radius, nsample, pad_to)
+    return _BallQueryGroup.apply(xyz, new_xyz, points, radius, nsample, pad_to, plan)
 
 
 def invert_index(idx, nkeys):
