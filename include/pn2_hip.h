@@ -8,8 +8,10 @@
  * pybind stub inside the reference's models/pointnet2_utils.py binds to.
  *
  * Conventions
- *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller
- *     (the library allocates nothing and keeps no global mutable state: reentrant);
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller; the library allocates
+ *     nothing and is reentrant.  Its only process state are idempotent per-device memos of host-side facts about
+ *     its own kernels (dynamic-LDS attribute raised, occupancy) and the PN2_TUNE_* developer knobs, which are read
+ *     from the environment once, at the first launch, never per call;
  *   - float tensors are fp32, index tensors int64, row-major contiguous, layouts as in the
  *     reference's free functions: xyz [B,N,3], points [B,N,D], idx [B,S] / [B,S,K];
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream),
@@ -159,10 +161,15 @@ int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int
 /* partial[P][2][C] -> train-mode BatchNorm coefficients scale = gamma*invstd, shift = beta -
  * mean*scale (biased variance), mean/invstd for backward, and the running-estimate update
  * running = (1-momentum)*running + momentum*batch (unbiased variance), nn.BatchNorm semantics;
- * num_batches_tracked (nullable, int64 device word) is incremented. */
+ * num_batches_tracked (nullable, int64 device word) is incremented.
+ * momentum_dev (nullable): one float in device memory read when the kernel RUNS and used instead of `momentum`,
+ * so that a launch replayed from a hipGraph follows the reference loop's per-epoch schedule
+ * (localfunctions.py:191-195).  A negative momentum = nn.BatchNorm(momentum=None): the cumulative moving
+ * average, factor 1 / num_batches_tracked, with the counter incremented by the caller BEFORE this launch
+ * (it is then only read here). */
 int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma, const float *beta,
-                    float eps, float momentum, float *running_mean, float *running_var, float *scale,
-                    float *shift, float *mean_out, float *invstd_out, long long *num_batches_tracked,
+                    float eps, float momentum, const float *momentum_dev, float *running_mean, float *running_var,
+                    float *scale, float *shift, float *mean_out, float *invstd_out, long long *num_batches_tracked,
                     pn2_stream_t stream);
 
 /* eval-mode coefficients from the running estimates */

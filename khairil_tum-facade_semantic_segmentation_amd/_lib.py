@@ -31,7 +31,7 @@ SIGNATURES = {
     "pn2_mlp_gemm_max_partials": [_ci],
     "pn2_mlp_gemm": [_vp, _ci, _ci, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _ci, _vp,
                      _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
-    "pn2_bn_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_bn_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_bn_eval_coeff": [_ci, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp],
     "pn2_bn_relu_out": [_vp, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_mlp_dw_partials": [_ci, _ci, _ci],

@@ -93,7 +93,7 @@ constexpr int BQ_CENT = BQ_THREADS / BQ_LPC;
 constexpr int BQ_STACK = 24;                   // members a lane can hold before the workgroup's wave falls back to extraction
 
 template <int NW>
-__global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
+__device__ __forceinline__ void ball_query_tile(unsigned logical, unsigned *bm, unsigned short *pre, unsigned short *mIdx, unsigned short *stack,
     const char *__restrict__ tables, size_t table_stride, int sorted_off, int rows_off, int rp, const float *__restrict__ new_xyz,
     int N, int S, int K, int D, float r2, int tiles_per_block, unsigned qpr_magic, int64_t *__restrict__ idx,
     float *__restrict__ grouped, int32_t *err_count)
@@ -101,12 +101,6 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
     constexpr int LPC = BQ_LPC, CENT = BQ_CENT;
     constexpr int WPL = NW / LPC;                // bitmap words per lane
     static_assert(WPL >= 4 && WPL % 4 == 0, "a lane's bitmap words are moved as 16-byte vectors");
-    __shared__ __attribute__((aligned(16))) unsigned bm[CENT * NW];                 // member bitmaps (bit = original index)
-    __shared__ __attribute__((aligned(16))) unsigned short pre[CENT * NW];          // members below each bitmap word
-    __shared__ __attribute__((aligned(16))) unsigned short mIdx[CENT * BQ_ROW];     // result indices, ascending (+ a dump slot)
-    __shared__ unsigned short stack[BQ_STACK * BQ_THREADS];                         // [slot][thread]: members a lane found
-
-    const unsigned logical = pn2::xcd_remap(blockIdx.x, gridDim.x);
     const int b = (int)(logical / (unsigned)tiles_per_block);
     const int tile = (int)(logical - (unsigned)b * (unsigned)tiles_per_block);
     const int tid = threadIdx.x, cl = tid >> 4, lg = tid & (LPC - 1);
@@ -136,10 +130,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
     auto test = [&](const v4i &p, bool valid) {
         const float x = __int_as_float(p.x), y = __int_as_float(p.y), z = __int_as_float(p.z);
         const float d = pn2::pair_sqdist(cx, cy, cz, cn, x, y, z, pn2::norm3(x, y, z));
-        bool hit = valid & !(d > r2);          // both sides evaluated: nothing for the compiler to sink under `valid`
-#ifdef PN2_EXP_NOHIT
-        hit = hit & (d < -1.0f);
-#endif
+        const bool hit = valid & !(d > r2);          // both sides evaluated: nothing for the compiler to sink under `valid`
         if (hit) {
             const unsigned i = (unsigned)p.w;
             atomicOr(&mybm[i >> 5], 1u << (i & 31u));
@@ -322,6 +313,24 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
         }
     }
     PN2_STAMP(5);
+}
+
+// One tile of 16 centroids per workgroup.  (Several tiles per workgroup one after the other, so that a tile's row
+// stores drain under the next tile's tests, measured slower -- 14.3 us for two, 21.9 us for four against 10.6 us: a
+// wave needs ~5.5 us for a tile even with a SIMD to itself, the launch is bound by that dependent chain and by the
+// vector instructions of the four waves sharing a SIMD, not by the stores.)
+template <int NW>
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
+    const char *__restrict__ tables, size_t table_stride, int sorted_off, int rows_off, int rp, const float *__restrict__ new_xyz,
+    int N, int S, int K, int D, float r2, int tiles_per_block, unsigned qpr_magic, int64_t *__restrict__ idx,
+    float *__restrict__ grouped, int32_t *err_count)
+{
+    __shared__ __attribute__((aligned(16))) unsigned bm[BQ_CENT * NW];                 // member bitmaps (bit = original index)
+    __shared__ __attribute__((aligned(16))) unsigned short pre[BQ_CENT * NW];          // members below each bitmap word
+    __shared__ __attribute__((aligned(16))) unsigned short mIdx[BQ_CENT * BQ_ROW];     // result indices, ascending (+ a dump slot)
+    __shared__ unsigned short stack[BQ_STACK * BQ_THREADS];                            // [slot][thread]: members a lane found
+    ball_query_tile<NW>(pn2::xcd_remap(blockIdx.x, gridDim.x), bm, pre, mIdx, stack, tables, table_stride, sorted_off, rows_off, rp, new_xyz,
+                        N, S, K, D, r2, tiles_per_block, qpr_magic, idx, grouped, err_count);
 }
 
 }  // namespace

@@ -55,7 +55,7 @@ __device__ __forceinline__ float wave_max_f(float v)
 __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
     int B, int N, int S, int K, int D, int ldg, float r2, int tiles_per_block, unsigned ldg_magic,
-    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
+    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *sP = reinterpret_cast<float4 *>(smem);                // [4096] cell-sorted (x, y, z, |p|^2)
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         }
     }
     const float mnx = -q[0], mny = -q[1], mnz = -q[2];
-    if (dbg == 4) return;
     // ---- (2) grid: cells at least R' wide.  |computed dist - true dist| <= 20 u M2 (u = 2^-24, M2 the
     //      largest squared norm: 3 roundings in the dot, 3 per norm, 2 in the sums, on values <= 4 M2);
     //      2^-19 M2 covers it, and 0.1 % on R' covers the rounding of the cell coordinates themselves.
@@ -221,7 +220,6 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     __syncthreads();
     PN2_STAMP(7);
 
-    if (dbg == 1) return;
     // From here on a centroid's 16 lanes depend on nothing but their own bitmap row, so there is no
     // workgroup barrier any more: groups that are still testing candidates (LDS / vector work) run
     // beside groups that already gather and store their rows (memory work).
@@ -269,7 +267,6 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     // LDS operations of one wave complete in order; the fence keeps the compiler from moving the reads up
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     PN2_STAMP(8);
-    if (dbg == 2) return;
     // ---- (7) the K lowest set bits, in order: lane l16 owns words 8*l16 .. 8*l16+7 ----------------------
     unsigned short *oi = mIdx + cl * K;
     int n;
@@ -299,7 +296,6 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     PN2_STAMP(9);
-    if (dbg == 3) return;
     // ---- (8) idx [b, s, 0..K) (padded with the first member, :104-106) -------------------------------
     {
         int64_t *orow = idx + ((size_t)b * S + my_s) * K;
@@ -382,15 +378,10 @@ int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *
     if (nwg > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
     const int qpr = (3 + D) >> 2;
     const unsigned magic = qpr > 1 ? (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u : 0u;     // e/qpr exact for e*qpr < 2^32
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ball_query_group_grid_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static pn2::PerDevice lds_memo;
+    if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(ball_query_group_grid_kernel), 160 * 1024, lds_memo)) return e;
     hipLaunchKernelGGL(ball_query_group_grid_kernel, dim3((unsigned)nwg), dim3(GR_THREADS), lds, stream, xyz, new_xyz, points,
-                       B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
+                       B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count);
     return PN2_LAUNCH_RC();
 }
 

@@ -92,7 +92,7 @@ template <int THREADS, int CPW>
 __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
     int B, int N, int S, int K, int D, int ldg, float r2, int tiles_per_block, unsigned cg_magic,
-    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
+    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count)
 {
     static_assert(CPW % 2 == 0, "centroids are processed in packed pairs");
     constexpr int WAVES = THREADS / PN2_WAVE;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
             }
         }
         __syncthreads();
-        const int nchunks = (dbg & 1) ? 0 : npad / PN2_WAVE;
+        const int nchunks = npad / PN2_WAVE;
         float4 pnext = pts[lane];
         for (int ch = 0; ch < nchunks; ++ch) {
             const float4 p = pnext;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
                 m[2 * q + 1] = __ballot(hit[2 * q + 1]);
                 any |= m[2 * q] | m[2 * q + 1];
             }
-            if (any && !(dbg & 2)) {
+            if (any) {
                 const int pidx = n0 + ch * PN2_WAVE + lane;
                 bool still = false;
 #pragma unroll
@@ -228,7 +228,6 @@ __global__ __launch_bounds__(THREADS) void ball_query_group_kernel(
         const int s = s0 + c;
         if (s >= S) break;
         int *lst = mylist + c * lcap;
-        if (dbg && cnt[c] == 0) { cnt[c] = 1; lst[0] = 0; }
         const int n = min(cnt[c], K);
         int64_t *orow = idx + ((size_t)b * S + s) * K;
         if (n == 0) {                                       // reference: IndexError at :59
@@ -368,7 +367,7 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(THREADS), lds, stream, xyz, new_xyz, points, B, N, S, K, D,
-                       ldg, r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
+                       ldg, r2, tiles, magic, idx, grouped, err_count);
     return PN2_LAUNCH_RC();
 }
 

@@ -38,7 +38,7 @@ template <bool ORDERED>
 __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
     int B, int N, int S, int K, int D, int ldg, float r2, int tiles_per_block, unsigned ldg_magic,
-    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count, int dbg)
+    int64_t *__restrict__ idx, float *__restrict__ grouped, int32_t *err_count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NT = (N + 32 * MF_SLICES - 1) / (32 * MF_SLICES) * (32 * MF_SLICES);   // slices of a multiple of 32
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
     const float *pxy = (half ? sY : sX) + quarter * NQ + l31;
     const float *pz = sZ + quarter * NQ + l31;
     const float *pn = sP + quarter * NQ + l31;
-    const int nsteps = (dbg & 1) ? 0 : NQ >> 5;
+    const int nsteps = NQ >> 5;
     const unsigned rows_valid = (unsigned)max(0, min(32, S - (s_base + grp * 32)));   // rows < rows_valid exist
     f32x16 zero16;
 #pragma unroll
@@ -130,7 +130,6 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(f[r]), 31);
         unsigned hits = ~bits & 0xffffu;
-        if (dbg & 2) hits = 0;
         if (!ORDERED) {
             if (__ballot(hits != 0)) {
                 const int j = quarter * NQ + t * 32 + l31;
@@ -189,7 +188,6 @@ __global__ __launch_bounds__(MF_THREADS) void ball_query_group_mfma_kernel(
     }
     if (ORDERED && lane < 32) cnt[(grp * 32 + lane) * MF_SLICES + quarter] = (unsigned)cntreg;
     __syncthreads();
-    if (dbg & 4) return;
 
     // ---- (1) every sub-list must be ascending: arrival order is, except that two hits of one
     //      32-point step may have landed swapped.  One thread per (centroid, quarter) checks and,
@@ -322,7 +320,7 @@ int launch_ball_query_mfma(const float *xyz, const float *new_xyz, const float *
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(MF_THREADS), lds, stream, xyz, new_xyz,
-                       points, B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count, pn2::tune_get("bq_dbg", 0));
+                       points, B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count);
     return PN2_LAUNCH_RC();
 }
 

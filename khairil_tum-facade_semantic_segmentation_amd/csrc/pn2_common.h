@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "pn2_hip.h"
 
 #pragma clang fp contract(off)
@@ -23,9 +25,31 @@
 
 namespace pn2 {
 
-// Developer tuning knob: PN2_TUNE_<NAME>=<int> in the environment overrides a launch heuristic
-// (read on every call: benchmarks only, never set in production).
+// Developer tuning knob: PN2_TUNE_<NAME>=<int> in the environment overrides a launch heuristic.  The environment
+// is scanned ONCE, when the first launcher asks (pn2_gather.hip); later changes of the environment are not seen,
+// and a launch costs no getenv.  Benchmarks only, never set in production.
 int tune_get(const char *name, int dflt);
+
+// Per-device memo of a small host-side fact about a kernel (its dynamic-LDS attribute has been raised, its
+// occupancy): the library keeps no other state, and this one is idempotent -- two threads racing on the same
+// slot compute the same value.  Devices beyond 64 share slots modulo 64 (the memo is then merely recomputed).
+struct PerDevice {
+    std::atomic<int> v[64];
+    PerDevice() { for (auto &x : v) x.store(-1, std::memory_order_relaxed); }
+    static int device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? (d & 63) : 0; }
+    int get() const { return v[device()].load(std::memory_order_acquire); }
+    void set(int x) { v[device()].store(x, std::memory_order_release); }
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); `memo` is the call site's static PerDevice.
+inline int ensure_dynamic_lds(const void *fn, int bytes, PerDevice &memo)
+{
+    if (memo.get() >= bytes) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    memo.set(bytes);
+    return 0;
+}
 
 // dW[n][k] = sum_p partial[p][n][k], db[n] = sum_p partial[p][n][K] over P slabs [N][K+1], fixed order
 // (pn2_mlp.hip); shared by the weight-gradient launchers.

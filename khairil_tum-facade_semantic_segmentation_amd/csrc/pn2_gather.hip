@@ -6,6 +6,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "pn2_common.h"
 
 namespace {
@@ -151,13 +155,37 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float *__res
 
 }  // namespace
 
+extern char **environ;
+
+namespace {
+struct TuneTable {
+    struct Entry { char key[48]; int value; };
+    Entry e[64];
+    int n = 0;
+    TuneTable()
+    {
+        for (char **p = environ; p && *p && n < 64; ++p) {
+            if (strncmp(*p, "PN2_TUNE_", 9) != 0) continue;
+            const char *eq = strchr(*p, '=');
+            if (!eq || eq - (*p + 9) >= (long)sizeof(e[0].key)) continue;
+            memset(e[n].key, 0, sizeof(e[n].key));
+            for (const char *c = *p + 9; c < eq; ++c) e[n].key[c - (*p + 9)] = (char)toupper((unsigned char)*c);
+            e[n].value = atoi(eq + 1);
+            ++n;
+        }
+    }
+};
+}  // namespace
+
 int pn2::tune_get(const char *name, int dflt)
 {
-    char key[64];
-    snprintf(key, sizeof(key), "PN2_TUNE_%s", name);
-    for (char *c = key; *c; ++c) *c = (char)toupper((unsigned char)*c);
-    const char *v = getenv(key);
-    return v ? atoi(v) : dflt;
+    static const TuneTable table;                    // built once, thread-safe (C++11 static initialisation)
+    if (table.n == 0) return dflt;
+    char key[48] = {0};
+    for (int i = 0; name[i] && i < 47; ++i) key[i] = (char)toupper((unsigned char)name[i]);
+    for (int i = 0; i < table.n; ++i)
+        if (strcmp(table.e[i].key, key) == 0) return table.e[i].value;
+    return dflt;
 }
 
 PN2_EXPORT int pn2_abi_version(void) { return PN2_ABI_VERSION; }

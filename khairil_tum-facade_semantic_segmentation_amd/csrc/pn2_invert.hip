@@ -176,13 +176,8 @@ PN2_EXPORT int pn2_invert_index(const int64_t *idx, int B, long long E, int Nkey
     if (B == 0) return PN2_OK;
     const size_t lds = ((size_t)(2 * Nkeys + 1) + (size_t)E) * sizeof(int);
     if (lds > 150 * 1024) return PN2_ERR_UNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(invert_index_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static pn2::PerDevice lds_memo;
+    if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(invert_index_kernel), 150 * 1024, lds_memo)) return e;
     hipLaunchKernelGGL(invert_index_kernel, dim3((unsigned)B), dim3(INV_THREADS), lds, static_cast<hipStream_t>(stream_), idx, E,
                        Nkeys, offsets, entries);
     return PN2_LAUNCH_RC();

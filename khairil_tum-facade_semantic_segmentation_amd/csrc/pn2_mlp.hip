@@ -827,12 +827,20 @@ __device__ __forceinline__ void strided_sum_pair_any(const float *__restrict__ a
 // double in a fixed order (deterministic).
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partial, int P, int C, double count,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, float momentum, float *__restrict__ running_mean,
+                                                          float eps, float momentum, const float *__restrict__ momentum_dev,
+                                                          float *__restrict__ running_mean,
                                                           float *__restrict__ running_var, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ mean_out,
                                                           float *__restrict__ invstd_out, long long *num_batches_tracked)
 {
-    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    // momentum: a device word when given (so that a captured launch follows the per-epoch schedule of the reference
+    // loop, localfunctions.py:191-195), else the host value; negative = nn.BatchNorm(momentum=None): the cumulative
+    // average 1 / num_batches_tracked, the counter then being incremented by the CALLER beforehand (all workgroups
+    // read it here)
+    if (momentum_dev) momentum = *momentum_dev;
+    const bool cumulative = momentum < 0.0f;
+    if (cumulative) momentum = (num_batches_tracked && *num_batches_tracked > 0) ? 1.0f / (float)*num_batches_tracked : 0.0f;
+    if (!cumulative && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     __shared__ double sS[32][33], sQ[32][33];
     const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 32 partial slices
     const int c = blockIdx.x * 32 + cl;
@@ -1582,13 +1590,9 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
             constexpr size_t LDS64_N = 2 * (64 * 68 + 128 * 68) * sizeof(float), LDS64_T = 2 * (64 * 68 + 64 * 132) * sizeof(float);
             constexpr size_t LDS64S_N = 2 * (32 * 68 + 128 * 68) * sizeof(float), LDS64S_T = 2 * (32 * 68 + 64 * 132) * sizeof(float);
 #define PN2_R32_ATTR(KERNEL) do { \
-            static bool attr_done = false; \
-            if (!attr_done) { \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                if (e != hipSuccess) return (int)e; \
-                attr_done = true; \
-            } } while (0)
+            static pn2::PerDevice lds_memo; \
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(KERNEL), 160 * 1024, lds_memo)) return e; \
+            } while (0)
 #define PN2_R32(P, W) do { \
         if (bk64) { \
             PN2_R32_ATTR((mlp_gemm_rows32_kernel<P, W, 64, 64>)); \
@@ -1615,7 +1619,7 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
 }
 
 PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma,
-                               const float *beta, float eps, float momentum, float *running_mean,
+                               const float *beta, float eps, float momentum, const float *momentum_dev, float *running_mean,
                                float *running_var, float *scale, float *shift, float *mean_out, float *invstd_out,
                                long long *num_batches_tracked, pn2_stream_t stream_)
 {
@@ -1624,7 +1628,7 @@ PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count,
     PN2_REQUIRE_PTR(shift);
     if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_), partial,
-                       P, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
+                       P, C, count, gamma, beta, eps, momentum, momentum_dev, running_mean, running_var, scale, shift, mean_out,
                        invstd_out, num_batches_tracked);
     return PN2_LAUNCH_RC();
 }

@@ -32,7 +32,6 @@ struct BwdArgs {
     float *stat_partial;                // [grid][2][K] (nullable)
     float *dw_partial;                  // [grid][N][K+1]
     int M, N, K;
-    int dbg;                            // developer switch (PN2_TUNE_FB_DBG): 1 skip dX MFMAs, 2 skip dW MFMAs
 };
 
 template <int NBLK, int KBLK, bool POOLED>
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 
         // ---- dX = dz * W : lane half h reduces n in [h NP/2, (h+1) NP/2)
-        if (p.gp && !(p.dbg & 1)) {
+        if (p.gp) {
 #pragma unroll
             for (int i = 0; i < DXPW; ++i) {
                 const int b = wave + FB_WAVES * i;
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
 #pragma unroll
         for (int i = 0; i < DWPW; ++i) {
             const int b = (FB_WAVES - 1 - wave) + FB_WAVES * i;
-            if (b < NDW && !(p.dbg & 2)) {
+            if (b < NDW) {
                 const int nb = b / KBLK, kb = b - nb * KBLK;
                 const float *dBase = &sD[(32 * half) * LDD + nb * 32 + l31];
                 const float *xBase = &sZ[(32 * half) * LDZ + kb * 32 + l31];
@@ -857,30 +856,30 @@ int fb_resident()
 template <int NBLK, int KBLK, bool POOLED>
 int fb_resident_of()
 {
-    static int cached = -1;
-    if (cached >= 0) return cached;
+    static pn2::PerDevice cached;                     // resident workgroups per CU on this device (attribute set with it)
+    if (cached.get() >= 0) return cached.get();
     constexpr int lds = fb_lds_bytes<NBLK, KBLK>();
     const void *fn = reinterpret_cast<const void *>(&mlp_bwd_fused_kernel<NBLK, KBLK, POOLED>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_fused_kernel<NBLK, KBLK, POOLED>, FB_THREADS, lds) != hipSuccess) return 0;
-    cached = n < 1 ? 0 : (n > 4 ? 4 : n);
-    return cached;
+    cached.set(n < 1 ? 0 : (n > 4 ? 4 : n));
+    return cached.get();
 }
 
 
 template <int NBLK, bool POOLED>
 int fs_resident_of()
 {
-    static int cached = -1;
-    if (cached >= 0) return cached;
+    static pn2::PerDevice cached;
+    if (cached.get() >= 0) return cached.get();
     constexpr int lds = fs_lds_bytes<NBLK>();
     const void *fn = reinterpret_cast<const void *>(&mlp_bwd_split_kernel<NBLK, POOLED>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_split_kernel<NBLK, POOLED>, FB_THREADS, lds) != hipSuccess) return 0;
-    cached = n < 1 ? 0 : (n > 4 ? 4 : n);
-    return cached;
+    cached.set(n < 1 ? 0 : (n > 4 ? 4 : n));
+    return cached.get();
 }
 
 // General split-role kernel: which shapes use it and with which tile (PN2_TUNE_FB_SPLIT2=0: off; bit 1 = the
@@ -896,15 +895,15 @@ int fs2_tile_rows(int nblk, int kblk)
 template <int NBLK, int KBLK, bool POOLED, int TR>
 int fs2_prepare()
 {
-    static int cached = -1;
-    if (cached >= 0) return cached;
+    static pn2::PerDevice cached;
+    if (cached.get() >= 0) return cached.get();
     constexpr int lds = fs2_lds_bytes<NBLK, KBLK, TR>();
     const void *fn = reinterpret_cast<const void *>(&mlp_bwd_split2_kernel<NBLK, KBLK, POOLED, TR, 8, 4>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_bwd_split2_kernel<NBLK, KBLK, POOLED, TR, 8, 4>, 768, lds) != hipSuccess) return 0;
-    cached = n < 1 ? 0 : 1;                           // one 12-wave workgroup per CU
-    return cached;
+    cached.set(n < 1 ? 0 : 1);                        // one 12-wave workgroup per CU
+    return cached.get();
 }
 
 template <int NBLK, int KBLK, int TR>
@@ -977,16 +976,16 @@ PN2_EXPORT int pn2_mlp_bwd_layer_partials(int M, int N, int K)
     if (per_cu < 1) return 0;
     int cus = 256;
     {
-        static int cached_cus = 0;
-        if (!cached_cus) {
+        static pn2::PerDevice cached_cus;
+        if (cached_cus.get() < 0) {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) == hipSuccess &&
                 hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-                cached_cus = n;
+                cached_cus.set(n);
             else
-                cached_cus = 256;
+                cached_cus.set(256);
         }
-        cus = cached_cus;
+        cus = cached_cus.get();
     }
     const int tiles = (M + tile_rows - 1) / tile_rows;
     int wgs = cus * pn2::tune_get("mlp_fb_wgs", per_cu);
@@ -1031,7 +1030,6 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.w = w; a.ldw = ldw; a.x = x; a.ldx = ldx;
     a.ascale = ascale; a.ashift = ashift; a.amean = amean; a.ainvstd = ainvstd; a.gp = gp; a.ldgp = ldgp;
     a.stat_partial = stat_partial; a.dw_partial = dw_partial; a.M = M; a.N = N; a.K = K;
-    a.dbg = pn2::tune_get("fb_dbg", 0);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int nblk = fb_blocks(N), kblk = fb_blocks(K > 128 ? 128 : K);
     int rc = PN2_ERR_UNSUPPORTED;

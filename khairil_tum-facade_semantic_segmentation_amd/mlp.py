@@ -49,6 +49,47 @@ def _gemm(lib, dev, x1, K1, x2, K2, pro, consts, argk, pool_k, w, ldw, w_is_kn, 
     _lib.check(rc, "pn2_mlp_gemm")
 
 
+def momentum_word(bn, dev):
+    """(host value, device word) of a BatchNorm module's momentum.  The kernels read the DEVICE word when they run,
+    so a step replayed from a hipGraph follows later changes of `bn.momentum` (the reference loop resets it every
+    epoch, localfunctions.py:191-195) -- provided the word is refreshed outside the graph: set_bn_momentum() does
+    that, and so does every eager forward.  momentum=None (cumulative moving average) has no word: (-1, None)."""
+    if bn.momentum is None:
+        return -1.0, None
+    m = float(bn.momentum)
+    word = bn.__dict__.get("_pn2_momentum")
+    if word is None or word[0].device != dev:
+        if torch.cuda.is_current_stream_capturing():
+            # a word created now would live in the graph's pool and be re-filled by every replay: the launch gets
+            # the host value instead (frozen).  ensure_momentum_words() before the capture avoids this.
+            return m, None
+        word = [torch.full((1,), m, dtype=torch.float32, device=dev), m]
+        bn.__dict__["_pn2_momentum"] = word
+    elif word[1] != m and not torch.cuda.is_current_stream_capturing():
+        word[0].fill_(m)
+        word[1] = m
+    return m, word[0]
+
+
+def ensure_momentum_words(module):
+    """Create the device words of every BatchNorm below `module` (call before capturing a graph)."""
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) and m.weight is not None and m.weight.is_cuda:
+            momentum_word(m, m.weight.device)
+
+
+def set_bn_momentum(module, momentum):
+    """The reference's per-epoch `m.momentum = ...` for every BatchNorm below `module` (localfunctions.py:187-195),
+    graph-safe: the device words the captured bn_finalize launches read are refreshed too."""
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.momentum = momentum
+            word = m.__dict__.get("_pn2_momentum")
+            if word is not None and momentum is not None:
+                word[0].fill_(float(momentum))
+                word[1] = float(momentum)
+
+
 class _MLPStack(torch.autograd.Function):
     """y = stack(x1 | x2).  args: bns (list of nn.BatchNorm modules, for running stats / mode),
     pool_k (0 = no pooling), x1 [M,K1], x2 [M,K2] or None, then per layer conv_w, conv_b, bn_w, bn_b."""
@@ -82,10 +123,12 @@ class _MLPStack(torch.autograd.Function):
                 bn = bns[l]
                 if training:
                     mean, invstd = torch.empty(Co, **f32), torch.empty(Co, **f32)
-                    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+                    mom, mom_dev = momentum_word(bn, dev)
                     track = bn.track_running_stats and bn.running_mean is not None
+                    if mom < 0.0 and track and bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)        # momentum=None: the kernel reads the bumped counter
                     rc = lib.pn2_bn_finalize(_ptr(stat), P, Co, float(M), _ptr(gamma), _ptr(beta), float(bn.eps), mom,
-                                             _ptr(bn.running_mean) if track else None,
+                                             _ptr(mom_dev), _ptr(bn.running_mean) if track else None,
                                              _ptr(bn.running_var) if track else None, _ptr(scale), _ptr(shift),
                                              _ptr(mean), _ptr(invstd),
                                              _ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else None,

@@ -10,6 +10,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import mlp
+
 
 def rotate_z_(blocks_cf, angles=None):
     """On-device form of provider.rotate_point_cloud_z applied to the xyz channels of a batch
@@ -74,7 +76,7 @@ class FlatAdam:
     learning rate live on the device (hipGraph replay).  HIP device only."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        from . import _lib
+        from . import _lib, mlp
         self._lib = _lib
         self.params = list(params)
         dev = self.params[0].device
@@ -138,6 +140,8 @@ class SemSegTrainer:
         self.prefetch = bool(prefetch_geometry) and on_gpu and hasattr(model, "compute_geometry")
         self._side = torch.cuda.Stream() if self.prefetch else None
         self._geo_next = None            # pyramid computed for the coming step
+        self._geo_next_src = None        # identity (data_ptr, version, shape) of the batch it was computed from
+        self._captured_mode = None       # (exchange, world) the graphs were captured for
         self._geo_event = None
         self._geo_cur = None             # (graph mode) static buffers the forward reads
         self._static_next_x = None
@@ -182,6 +186,23 @@ class SemSegTrainer:
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.group)
         return 1
+
+    def set_lr(self, lr):
+        """Per-epoch learning rate of the reference loop (localfunctions.py:187-190); graph-safe (device scalar)."""
+        if self.flat_adam is not None:
+            self.flat_adam.set_lr(lr)
+        else:
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
+
+    def set_bn_momentum(self, momentum):
+        """Per-epoch BatchNorm momentum of the reference loop (localfunctions.py:191-195); graph-safe: the captured
+        bn_finalize launches read it from device words (mlp.momentum_word)."""
+        mlp.set_bn_momentum(self.model, momentum)
+
+    @staticmethod
+    def _identity(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
 
     def _exchange(self):
         """True when gradients go through the packed-buffer all-reduce.  PN2_FORCE_DP_PATH=1 takes
@@ -228,12 +249,15 @@ class SemSegTrainer:
         geo = None
         if self.prefetch:
             main = torch.cuda.current_stream()
-            if self._geo_next is None:                   # first step: nothing was prefetched
+            # the prefetched pyramid belongs to the tensor it was computed from: any other batch (or the same tensor
+            # modified in place since) gets its own pyramid now instead of silently grouping with foreign indices
+            if self._geo_next is None or self._geo_next_src != self._identity(blocks_cf):
                 self._geo_next = self._launch_prefetch(blocks_cf)
             main.wait_stream(self._side)
             geo, self._geo_next = self._geo_next, None
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._geo_next = self._launch_prefetch(nxt)  # overlaps with everything below
+            self._geo_next_src = self._identity(nxt)
             for t in self._geo_next:
                 if t is not None:
                     t.record_stream(self._side)
@@ -244,6 +268,9 @@ class SemSegTrainer:
 
     def _capture(self, blocks_cf, target):
         exchange = self._exchange()
+        mlp.ensure_momentum_words(self.model)                   # outside the graph: replays then follow set_bn_momentum()
+        self._captured_mode = (exchange, self._world())
+        self._geo_next_src = self._identity(blocks_cf)          # (prefetch) `cur` will hold this batch's pyramid
         self._static_x = blocks_cf.clone()
         self._static_y = target.clone()
         if self.prefetch:
@@ -313,12 +340,24 @@ class SemSegTrainer:
             torch.cuda.synchronize()
             self._geo_next = None
             self._capture(blocks_cf, target)
+        if self._captured_mode != (self._exchange(), self._world()):
+            raise RuntimeError("the step was captured for %s (gradient exchange, world size) but now runs with %s: "
+                               "capture (prepare()) before init_process_group creates no all-reduce -- call prepare() "
+                               "after the process group exists, or build a new SemSegTrainer"
+                               % (self._captured_mode, (self._exchange(), self._world())))
         if blocks_cf.data_ptr() != self._static_x.data_ptr():
             self._static_x.copy_(blocks_cf)
         if target.data_ptr() != self._static_y.data_ptr():
             self._static_y.copy_(target)
         if self.prefetch:
-            self._static_next_x.copy_(blocks_cf if next_blocks_cf is None else next_blocks_cf)
+            if self._geo_next_src != self._identity(blocks_cf):
+                # the pyramid in `cur` was computed for another batch (the caller did not announce this one as
+                # next_blocks_cf): compute this batch's pyramid now, on the main stream, before the replay reads it
+                with torch.no_grad():
+                    self._geo_flat.copy_(self._pack_geometry(self.model.compute_geometry(self._static_x)))
+            nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
+            self._static_next_x.copy_(nxt)
+            self._geo_next_src = self._identity(nxt)
         self._g_fwd_bwd.replay()
         if self._g_opt is not None:
             dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)

@@ -192,3 +192,91 @@ def test_two_rank_exchange_on_one_gpu(tmp_path):
     assert np.array_equal(p0, p1)
     l0, l1 = np.load(tmp_path / "loss_rank0.npy"), np.load(tmp_path / "loss_rank1.npy")
     assert np.isfinite(l0).all() and np.isfinite(l1).all() and not np.array_equal(l0, l1)
+
+
+def test_schedules_reach_a_captured_step(monkeypatch):
+    """The reference loop resets the learning rate and every BatchNorm momentum each epoch
+    (localfunctions.py:187-195).  After the step has been captured into hipGraphs both must still take effect:
+    the replayed launches read them from device words.  One step in each mode from the same state, after the
+    schedule moved: identical running statistics (they depend on the momentum only) and parameters."""
+    torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
+    from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
+    results = {}
+    for graphs in (False, True):
+        model = fresh_model()
+        tr = SemSegTrainer(model, class_weight=cw, graphs=graphs, prefetch_geometry=False, graph_warmup=0, lr=1e-3)
+        tr.step(xs[0], ys[0])                              # graph mode: captures here with momentum 0.1, lr 1e-3
+        tr.step(xs[0], ys[0])
+        tr.set_lr(2.5e-4)
+        tr.set_bn_momentum(0.01)
+        assert model.sa2.mlp_bns[1].momentum == 0.01
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        tr.step(xs[1], ys[1])
+        torch.cuda.synchronize()
+        results[graphs] = (before, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    for k in results[False][1]:
+        a0, a1 = results[False][0][k].double(), results[False][1][k].double()
+        b0, b1 = results[True][0][k].double(), results[True][1][k].double()
+        if "running_" in k:
+            # new = (1 - m) * old + m * batch  ->  the step's relative move identifies m (0.01, not the captured 0.1)
+            move_e, move_g = (a1 - a0), (b1 - b0)
+            scale = float(move_e.abs().max()) + 1e-12
+            assert float((move_e - move_g).abs().max()) <= 0.05 * scale + 1e-7, k
+        elif "num_batches" in k:
+            assert torch.equal(a1, b1)
+    # the parameter update of that step scales with the learning rate: compare update norms
+    def upd(res):
+        return sum(float((res[1][k].double() - res[0][k].double()).pow(2).sum()) for k in res[1]
+                   if "running_" not in k and "num_batches" not in k) ** 0.5
+    ue, ug = upd(results[False]), upd(results[True])
+    assert abs(ue - ug) <= 0.05 * ue, (ue, ug)
+    # and momentum really moved: with the captured 0.1 the running mean would have moved ~10x as far
+    k = "sa1.mlp_bns.0.running_mean"
+    tr_model = fresh_model()
+    tr2 = SemSegTrainer(tr_model, class_weight=cw, graphs=True, prefetch_geometry=False, graph_warmup=0, lr=1e-3)
+    tr2.step(xs[0], ys[0]); tr2.step(xs[0], ys[0])
+    b0 = tr_model.state_dict()[k].detach().clone()
+    tr2.step(xs[1], ys[1])
+    torch.cuda.synchronize()
+    big = float((tr_model.state_dict()[k] - b0).abs().max())
+    small = float((results[True][1][k] - results[True][0][k]).abs().max())
+    assert small < 0.3 * big, (small, big)
+
+
+def test_unannounced_batch_gets_its_own_pyramid(monkeypatch):
+    """With geometry prefetch a step groups with the pyramid computed one call earlier.  A caller that does not
+    announce the next batch (next_blocks_cf) and then trains on a different one must not get the previous batch's
+    indices: first-step losses on alternating batches equal the eager / no-prefetch ones."""
+    torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
+    from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
+
+    def run(**mode):
+        tr = SemSegTrainer(fresh_model(), class_weight=cw, graph_warmup=0, **mode)
+        out = [float(tr.step(xs[i % 2], ys[i % 2])) for i in range(4)]      # no next_blocks_cf
+        torch.cuda.synchronize()
+        return np.array(out)
+    ref = run(graphs=False, prefetch_geometry=False)
+    for mode in (dict(graphs=False, prefetch_geometry=True), dict(graphs=True, prefetch_geometry=True)):
+        got = run(**mode)
+        assert abs(got[0] - ref[0]) <= 1e-4 and abs(got[1] - ref[1]) <= 5e-3, (mode, got, ref)
+        np.testing.assert_allclose(got, ref, rtol=2e-2, err_msg=str(mode))
+
+
+def test_bn_momentum_none_is_the_cumulative_average():
+    """nn.BatchNorm(momentum=None): running = cumulative average over the batches seen."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd import mlp
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    conv = torch.nn.Conv1d(8, 16, 1).to(dev)
+    bn = torch.nn.BatchNorm1d(16, momentum=None).to(dev)
+    ref_bn = torch.nn.BatchNorm1d(16, momentum=None).to(dev)
+    for step in range(3):
+        x = torch.randn(4096, 8, device=dev) * (1.0 + step) + step
+        y = mlp.mlp_stack(x, None, [conv], [bn], 0)
+        z = torch.nn.functional.conv1d(x.t().unsqueeze(0), conv.weight, conv.bias)
+        yr = torch.relu(ref_bn(z)).squeeze(0).t()
+        assert float((y - yr).abs().max()) <= 1e-4
+    assert int(bn.num_batches_tracked) == 3
+    assert float((bn.running_mean - ref_bn.running_mean).abs().max()) <= 1e-5
+    assert float((bn.running_var - ref_bn.running_var).abs().max()) <= 1e-4 * float(ref_bn.running_var.abs().max())
