@@ -11,8 +11,11 @@ configs[1]).  Rank 0 prints ONE JSON line; `roofline` prices the query_ball_poin
 of SA1 (the kernel the north_star names) against the HBM roof; `cpu_baseline` is the CPU oracle
 timed on the host cores on a bounded sample (N=1 only)."""
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,7 +40,8 @@ def ball_group_algorithmic_bytes(B, N, S, K, D):
 
 def cpu_baseline(seconds_budget=12.0):
     """The CPU oracle (oracle/: C index ops + torch CPU network), fwd+bwd+Adam on the same
-    synthetic blocks.  Bounded: at most 3 steps of B=16, stops once `seconds_budget` is spent."""
+    synthetic blocks.  Bounded: at most 3 steps of B=16, stops once `seconds_budget` is spent; plus the legs
+    SURVEY.md 8(d) lists: one B=1 step (BASELINE configs[0]) and query_ball_point+group / FPS alone."""
     from khairil_tum_facade_semantic_segmentation_amd import synth
     from oracle import pn2_oracle as orc
     orc.build()
@@ -56,9 +60,49 @@ def cpu_baseline(seconds_budget=12.0):
         net.train_step(cf, labels, starts, opt)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n * PER_GPU_BATCH * BLOCK_POINTS / dt, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": "%d fwd+bwd+Adam step(s) of %dx%dx%d cube blocks, %.1f s, oracle (C index ops + torch CPU)"
-                      % (n, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt)}
+    out = {"value": n * PER_GPU_BATCH * BLOCK_POINTS / dt, "unit": "points/s", "cores": threads, "kind": "port",
+           "sample": "%d fwd+bwd+Adam step(s) of %dx%dx%d cube blocks, %.1f s, oracle (C index ops + torch CPU)"
+                     % (n, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt)}
+    # configs[0]: one 4096x9 block, one fwd+bwd(+Adam) step
+    t0 = time.perf_counter()
+    net.train_step(cf[:1], labels[:1], [s[:1] for s in starts], opt)
+    out["b1_step_points_per_s"] = BLOCK_POINTS / (time.perf_counter() - t0)
+    # the hot path alone, B = 16: FPS 4096 -> 1024, then query_ball_point + grouping (r = 0.1, K = 32, D = 9)
+    xyz = np.ascontiguousarray(blocks[:, :, :3])
+    t0 = time.perf_counter()
+    fps = orc.farthest_point_sample(xyz, 1024, starts[0])
+    t_fps = time.perf_counter() - t0
+    cxyz = orc.index_points(xyz, fps)
+    t0 = time.perf_counter()
+    idx = orc.query_ball_point(0.1, 32, xyz, cxyz)
+    orc.group_points(xyz, cxyz, blocks, idx)
+    t_ball = time.perf_counter() - t0
+    out["fps_input_points_per_s"] = PER_GPU_BATCH * BLOCK_POINTS / t_fps
+    out["ball_query_group_input_points_per_s"] = PER_GPU_BATCH * BLOCK_POINTS / t_ball
+    return out
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the kernel the roofline prices: a PMC traffic figure is only quoted while it
+    was measured on exactly these sources."""
+    h = hashlib.sha256()
+    for name in ("pn2_ball_binned.hip", "pn2_ball_bin.h", "pn2_common.h"):
+        with open(os.path.join(REPO, "khairil_tum-facade_semantic_segmentation_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run as
+    fresh child processes -- this parent has not touched the GPU -- and pass their output and exit code through."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -76,10 +120,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                       # before anything here touches the GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
         args.gpus = world
+    if os.environ.get("PN2_BENCH_DRY_LAUNCH") == "1":     # launcher rehearsal (tests/test_bench_launcher_cpu.py): no GPU work
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world}), flush=True)
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -131,52 +178,104 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(loss).item(), "training step produced a non-finite loss"
 
-    # roofline of the north_star kernel: SA1 query_ball_point+group at B=16, N=4096, S=1024, K=32, D=9,
-    # HIP events on the launch stream, same resident inputs as the timed steps.
+    # roofline of the north_star kernel: SA1 query_ball_point+group at B=16, N=4096, S=1024, K=32, D=9, same
+    # resident inputs as the timed steps.  The product path (models.pointnet2_utils.sample_and_group) is
+    # FPS-with-plan -> pack rows -> pn2_ball_query_group_planned; `kernel_ms` is the average duration of
+    # pn2_ball_query_group_planned's launch (it issues one kernel) over `reps` launches running back to back in a
+    # captured graph, between HIP events on the launch stream.  What building the plan costs is reported beside it
+    # (the producer launches: binning + row packing; and what the binning launch adds to an FPS call), and so is the
+    # self-contained entry pn2_ball_query_group, which needs no workspace and keeps its own kernel.
     pts = x.permute(0, 2, 1).contiguous()
     xyz = pts[:, :, :3].contiguous()
-    _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, 1024)
+    start = torch.zeros(PER_GPU_BATCH, dtype=torch.long, device=dev)
+    _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, 1024, 0.1, CHANNELS, start)
+    plan.pack_rows(xyz, pts)
+    lib = _lib.load()
+    idx_buf = torch.empty((PER_GPU_BATCH, 1024, 32), dtype=torch.int64, device=dev)
+    grp_buf = torch.empty((PER_GPU_BATCH, 1024, 32, 3 + CHANNELS), dtype=torch.float32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def planned():
+        rc = lib.pn2_ball_query_group_planned(0.1, 32, plan.buf.data_ptr(), xyz.data_ptr(), new_xyz.data_ptr(), pts.data_ptr(),
+                                              PER_GPU_BATCH, BLOCK_POINTS, 1024, CHANNELS, idx_buf.data_ptr(), grp_buf.data_ptr(),
+                                              0, err.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0, rc
+
+    def selfcontained():
+        rc = lib.pn2_ball_query_group(0.1, 32, xyz.data_ptr(), new_xyz.data_ptr(), pts.data_ptr(), PER_GPU_BATCH, BLOCK_POINTS,
+                                      1024, CHANNELS, idx_buf.data_ptr(), grp_buf.data_ptr(), 0, err.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0, rc
+
+    def producers():
+        rc = lib.pn2_ball_plan(0.1, xyz.data_ptr(), new_xyz.data_ptr(), pts.data_ptr(), PER_GPU_BATCH, BLOCK_POINTS, 1024,
+                               CHANNELS, plan.buf.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0, rc
+
+    def fps(with_plan):
+        o = torch.empty((PER_GPU_BATCH, 1024), dtype=torch.int64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if with_plan:
+            rc = lib.pn2_farthest_point_sample_plan(xyz.data_ptr(), PER_GPU_BATCH, BLOCK_POINTS, 1024, start.data_ptr(),
+                                                    o.data_ptr(), new_xyz.data_ptr(), 0.1, CHANNELS, plan.buf.data_ptr(),
+                                                    err.data_ptr(), st)
+        else:
+            rc = lib.pn2_farthest_point_sample(xyz.data_ptr(), PER_GPU_BATCH, BLOCK_POINTS, 1024, start.data_ptr(), o.data_ptr(),
+                                               new_xyz.data_ptr(), err.data_ptr(), st)
+        assert rc == 0, rc
+
+    def back_to_back_ms(fn, reps):
+        """average duration of `reps` calls of fn running back to back (one captured graph, so that the host's
+        submission rate does not matter), median of 5 replays: what rocprofv3 --kernel-trace reports per launch"""
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        times = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            graph.replay()
+            b.record()
+            torch.cuda.synchronize(dev)
+            times.append(a.elapsed_time(b) / reps)
+        del graph
+        return float(np.median(times))
+
     reps = 50
-    for _ in range(5):
-        ops._ball_query_group_raw(0.1, 32, xyz, new_xyz, pts, True)
-    torch.cuda.synchronize(dev)
-    # (i) one event pair per launch: includes the launch latency of an idle queue
+    k_ms = back_to_back_ms(planned, reps)
+    # one event pair per launch: includes the launch latency of an idle queue
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record()
-        ops._ball_query_group_raw(0.1, 32, xyz, new_xyz, pts, True)
+        planned()
         b.record()
     torch.cuda.synchronize(dev)
     k_ms_single = float(np.median([a.elapsed_time(b) for a, b in ev]))
-    # (ii) the average duration of `reps` launches running back to back (a captured graph, so that the host's
-    # submission rate does not matter): what rocprofv3 --kernel-trace reports per launch
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
-        for _ in range(reps):
-            ops._ball_query_group_raw(0.1, 32, xyz, new_xyz, pts, True)
-    torch.cuda.current_stream(dev).wait_stream(side)
-    graph.replay()
-    torch.cuda.synchronize(dev)
-    times = []
-    for _ in range(5):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        graph.replay()
-        b.record()
-        torch.cuda.synchronize(dev)
-        times.append(a.elapsed_time(b) / reps)
-    k_ms = float(np.median(times))
-    del graph
+    self_ms = back_to_back_ms(selfcontained, reps)
+    prod_ms = back_to_back_ms(producers, reps)
+    fps_plain_ms = back_to_back_ms(lambda: fps(False), 10)
+    fps_plan_ms = back_to_back_ms(lambda: fps(True), 10)
+    assert int(err.item()) == 0
     algo = ball_group_algorithmic_bytes(PER_GPU_BATCH, BLOCK_POINTS, 1024, 32, CHANNELS)
     achieved = algo / (k_ms * 1e-3) / 1e9
-    # HBM traffic of that launch cannot be read from inside this process: it is the rocprofv3 --pmc
-    # measurement committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
+    # HBM traffic of that launch cannot be read from inside this process: it is the rocprofv3 --pmc measurement
+    # committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), quoted only while the
+    # kernel sources are the ones it was measured on
     traffic = None
     try:
-        with open(os.path.join(REPO, "profiles", "r01", "ball_query_pmc.json")) as fh:
-            traffic = json.load(fh).get("traffic_bytes_per_launch")
+        with open(os.path.join(REPO, "profiles", "r02", "ball_query_pmc.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("source_sha256") == kernel_source_hash():
+            traffic = pmc.get("traffic_bytes_per_launch")
     except (OSError, ValueError):
         pass
 
@@ -199,10 +298,17 @@ def main():
                                    "npoint=[1024,256,64,16] nsample=32, 18 classes (BASELINE configs[1])" % args.kind,
                        "global_batch": world * PER_GPU_BATCH, "points_per_block": BLOCK_POINTS,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "ball_query_group_grid_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "ball_query_binned_kernel = every launch of pn2_ball_query_group_planned "
+                                   "(SA1: N=4096,S=1024,K=32,D=9,B=16, %s)" % args.kind,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": k_ms,
-                         "kernel_ms_single_launch": k_ms_single},
+                         "kernel_ms_single_launch": k_ms_single,
+                         "plan_standalone_ms": prod_ms, "plan_with_fps_ms": fps_plan_ms - fps_plain_ms,
+                         "fps_kernel_ms": fps_plain_ms, "self_contained_entry_ms": self_ms,
+                         "frac_with_standalone_plan": algo / ((k_ms + prod_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_with_fps_plan_and_pack": algo / ((k_ms + prod_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_self_contained_entry": algo / (self_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -76,12 +76,12 @@ int pn2_ball_query_group(double radius, int nsample, const float *xyz, const flo
  * caller-owned workspace `plans` (B * pn2_ball_plan_bytes(N, S, D) bytes, 128-byte aligned; layout in
  * csrc/pn2_ball_bin.h): the points sorted into a uniform grid whose cells are at least radius wide, per centroid the
  * nine runs of that array holding the 27 neighbouring cells, and the packed rows [x, y, z, feats] the grouping
- * gathers from.  pn2_farthest_point_sample_plan = pn2_farthest_point_sample whose kernel also writes the sort and
- * the runs from the registers it holds (new_xyz required); pn2_ball_pack_rows adds the packed rows (needed when
+ * gathers from.  pn2_farthest_point_sample_plan = pn2_farthest_point_sample followed, on the same stream, by the
+ * launch that writes the sort and the runs (new_xyz required); pn2_ball_pack_rows adds the packed rows (needed when
  * pn2_ball_query_group_planned is asked for `grouped` with the dense pitch 3+D, (3+D) % 4 == 0);
  * pn2_ball_plan = the stand-alone producer of all three for a given new_xyz.  pn2_ball_query_group_planned is
  * pn2_ball_query_group on such a plan: same outputs, bit for bit.  Limits: N <= 8192 (pn2_ball_plan_bytes
- * returns 0 beyond), 1024 < N for the FPS form. */
+ * returns 0 beyond). */
 long long pn2_ball_plan_bytes(int N, int S, int D);
 int pn2_farthest_point_sample_plan(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out_idx,
                                    float *new_xyz, double radius, int D, void *plans, int32_t *err_count,

@@ -335,6 +335,20 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
 
 }  // namespace
 
+namespace pn2 {
+// the binning / planning kernel alone (also the second launch of pn2_farthest_point_sample_plan)
+int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S, int D, float r2, char *plans, hipStream_t stream)
+{
+    const size_t lds = bin_lds_bytes<1024>();
+    const size_t stride = bin_block_bytes(N, S, D);
+    if (N <= 1024) hipLaunchKernelGGL(ball_bin_kernel<1>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
+    else if (N <= 2048) hipLaunchKernelGGL(ball_bin_kernel<2>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
+    else if (N <= 4096) hipLaunchKernelGGL(ball_bin_kernel<4>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
+    else hipLaunchKernelGGL(ball_bin_kernel<8>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
+    return PN2_LAUNCH_RC();
+}
+}  // namespace pn2
+
 // ---- C ABI ---------------------------------------------------------------------------------------------------
 PN2_EXPORT long long pn2_ball_plan_bytes(int N, int S, int D)
 {
@@ -372,15 +386,7 @@ PN2_EXPORT int pn2_ball_plan(double radius, const float *xyz, const float *new_x
     if ((reinterpret_cast<uintptr_t>(plans) & 127) != 0) return PN2_ERR_SHAPE;
     if (B == 0) return PN2_OK;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const size_t lds = pn2::bin_lds_bytes<1024>();
-    const size_t stride = pn2::bin_block_bytes(N, S, D);
-    char *t = static_cast<char *>(plans);
-    if (N <= 1024) hipLaunchKernelGGL(ball_bin_kernel<1>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, t, stride);
-    else if (N <= 2048) hipLaunchKernelGGL(ball_bin_kernel<2>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, t, stride);
-    else if (N <= 4096) hipLaunchKernelGGL(ball_bin_kernel<4>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, t, stride);
-    else hipLaunchKernelGGL(ball_bin_kernel<8>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, t, stride);
-    const int rc = PN2_LAUNCH_RC();
+    const int rc = pn2::launch_ball_bin(xyz, new_xyz, B, N, S, D, r2, static_cast<char *>(plans), static_cast<hipStream_t>(stream_));
     if (rc != PN2_OK) return rc;
     return pn2_ball_pack_rows(xyz, points, B, N, S, D, plans, stream_);
 }

@@ -2,20 +2,22 @@
 // (models/pointnet2_utils.py:63-84): one workgroup per 4096-point block, the points and their
 // running min-distance live in registers for the whole kernel, one workgroup barrier per
 // iteration.  Latency-bound by construction (npoint dependent argmax steps); see DESIGN.md.
-#include "pn2_ball_bin.h"
+#include "pn2_common.h"
+
+namespace pn2 {
+int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S, int D, float r2, char *plans, hipStream_t stream);
+}
 
 namespace {
 
 // T threads, P consecutive points per thread (thread t owns points t*P .. t*P+P-1, so lane
 // order == index order and "first lane with the max" == "lowest index with the max", the tie
 // rule of torch.max (:83)).
-// PLAN: the same workgroup then builds the block's ball-query plan (pn2_ball_bin.h) for radius^2 = plan_r2 from
-// the registers it already holds and the centroids it has just written.
-template <int T, int P, bool LDS_XYZ, bool PLAN>
+template <int T, int P, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
                                                 const int64_t *__restrict__ start,
-                                                int64_t *__restrict__ out_idx, float *new_xyz,
-                                                int32_t *err_count, float plan_r2, int plan_d, char *plans, size_t plan_stride)
+                                                int64_t *__restrict__ out_idx, float *__restrict__ new_xyz,
+                                                int32_t *err_count)
 {
     constexpr int W = T / PN2_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,61 +94,28 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
         }
         far = widx;                                                              // :83
     }
-    if (PLAN) {
-        __syncthreads();            // the centroids (stored by thread 0) are visible to the workgroup; LDS is free again
-        pn2::bin_block<T, P>(px, py, pz, N, plan_r2, plan_d, new_xyz + (size_t)b * npoint * 3, npoint, smem, plans + (size_t)b * plan_stride);
-    }
 }
 
 template <int T, int P>
 int launch_fps(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out_idx,
-               float *new_xyz, int32_t *err_count, hipStream_t stream, float plan_r2 = 0.0f, int plan_d = 0, char *plans = nullptr,
-               size_t plan_stride = 0)
+               float *new_xyz, int32_t *err_count, hipStream_t stream)
 {
     const size_t slots = 2 * 16 * sizeof(unsigned long long);
-    constexpr bool lds_xyz = (size_t)T * P * sizeof(float4) <= 128 * 1024;
-    size_t lds = slots + (lds_xyz ? (size_t)T * P * sizeof(float4) : 0);
-    if (plans) {
-        if constexpr (T >= 256 && T <= 1024 && P <= 8) {
-            if (lds < pn2::bin_lds_bytes<T>()) lds = pn2::bin_lds_bytes<T>();
-            auto k = fps_kernel<T, P, lds_xyz, true>;
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return (int)e;
-            }
-            hipLaunchKernelGGL(k, dim3(B), dim3(T), lds, stream, xyz, N, npoint, start, out_idx, new_xyz, err_count, plan_r2, plan_d, plans,
-                               plan_stride);
-            return PN2_LAUNCH_RC();
-        } else {
-            return PN2_ERR_UNSUPPORTED;
+    const bool lds_xyz = (size_t)T * P * sizeof(float4) <= 128 * 1024;
+    if (lds_xyz) {
+        const size_t lds = slots + (size_t)T * P * sizeof(float4);
+        auto k = fps_kernel<T, P, true>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
         }
+        hipLaunchKernelGGL(k, dim3(B), dim3(T), lds, stream, xyz, N, npoint, start, out_idx, new_xyz, err_count);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(B), dim3(T), slots, stream, xyz, N, npoint, start,
+                           out_idx, new_xyz, err_count);
     }
-    auto k = fps_kernel<T, P, lds_xyz, false>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, dim3(B), dim3(T), lds, stream, xyz, N, npoint, start, out_idx, new_xyz, err_count, 0.0f, 0, nullptr, (size_t)0);
     return PN2_LAUNCH_RC();
-}
-
-int dispatch_fps(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out_idx, float *new_xyz, int32_t *err_count,
-                 hipStream_t stream, float plan_r2, int plan_d, char *plans, size_t plan_stride)
-{
-#define PN2_FPS_CASE(T, P) \
-    if (N <= (T) * (P)) return launch_fps<T, P>(xyz, B, N, npoint, start, out_idx, new_xyz, err_count, stream, plan_r2, plan_d, plans, plan_stride)
-    PN2_FPS_CASE(64, 1);
-    PN2_FPS_CASE(64, 2);
-    PN2_FPS_CASE(64, 4);
-    PN2_FPS_CASE(128, 4);
-    PN2_FPS_CASE(256, 4);
-    PN2_FPS_CASE(512, 4);
-    PN2_FPS_CASE(512, 8);
-    PN2_FPS_CASE(1024, 8);
-    PN2_FPS_CASE(1024, 16);
-    PN2_FPS_CASE(1024, 32);
-#undef PN2_FPS_CASE
-    return PN2_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -161,23 +130,39 @@ PN2_EXPORT int pn2_farthest_point_sample(const float *xyz, int B, int N, int npo
     if (B < 0 || N <= 0 || npoint < 0) return PN2_ERR_SHAPE;
     if (N > 32768) return PN2_ERR_UNSUPPORTED;
     if (B == 0 || npoint == 0) return PN2_OK;
-    return dispatch_fps(xyz, B, N, npoint, start, out_idx, new_xyz, err_count, static_cast<hipStream_t>(stream_), 0.0f, 0, nullptr, 0);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define PN2_FPS_CASE(T, P) \
+    if (N <= (T) * (P)) return launch_fps<T, P>(xyz, B, N, npoint, start, out_idx, new_xyz, err_count, stream)
+    PN2_FPS_CASE(64, 1);
+    PN2_FPS_CASE(64, 2);
+    PN2_FPS_CASE(64, 4);
+    PN2_FPS_CASE(128, 4);
+    PN2_FPS_CASE(256, 4);
+    PN2_FPS_CASE(512, 4);
+    PN2_FPS_CASE(512, 8);
+    PN2_FPS_CASE(1024, 8);
+    PN2_FPS_CASE(1024, 16);
+    PN2_FPS_CASE(1024, 32);
+#undef PN2_FPS_CASE
+    return PN2_ERR_UNSUPPORTED;
 }
 
+// farthest_point_sample + the ball-query plan of every block (csrc/pn2_ball_bin.h) for `radius`: the sampling
+// kernel, then the one-workgroup-per-block binning kernel on the same stream.  (Building the plan in the tail of the
+// sampling kernel itself -- the block is in its registers -- was measured: the tail takes 8.6 us, but the extra
+// live state changes how the compiler schedules the latency-bound sampling loop, +0.028 us on each of its 1024
+// iterations = +29 us per call against 11 us for the separate kernel.)
 PN2_EXPORT int pn2_farthest_point_sample_plan(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out_idx,
                                               float *new_xyz, double radius, int D, void *plans, int32_t *err_count,
                                               pn2_stream_t stream_)
 {
-    PN2_REQUIRE_PTR(xyz);
-    PN2_REQUIRE_PTR(start);
-    PN2_REQUIRE_PTR(out_idx);
     PN2_REQUIRE_PTR(new_xyz);
     PN2_REQUIRE_PTR(plans);
-    if (B < 0 || N <= 0 || npoint <= 0 || D < 0) return PN2_ERR_SHAPE;
-    if (N > 8192 || N <= 1024) return PN2_ERR_UNSUPPORTED;          // the shapes the planned ball query covers
+    if (D < 0 || npoint <= 0) return PN2_ERR_SHAPE;
+    if (N > 8192) return PN2_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(plans) & 127) != 0) return PN2_ERR_SHAPE;
-    if (B == 0) return PN2_OK;
+    const int rc = pn2_farthest_point_sample(xyz, B, N, npoint, start, out_idx, new_xyz, err_count, stream_);
+    if (rc != PN2_OK || B == 0) return rc;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
-    return dispatch_fps(xyz, B, N, npoint, start, out_idx, new_xyz, err_count, static_cast<hipStream_t>(stream_), r2, D,
-                        static_cast<char *>(plans), pn2::bin_block_bytes(N, npoint, D));
+    return pn2::launch_ball_bin(xyz, new_xyz, B, N, npoint, D, r2, static_cast<char *>(plans), static_cast<hipStream_t>(stream_));
 }

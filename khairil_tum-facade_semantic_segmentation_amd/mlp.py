@@ -145,19 +145,41 @@ class _MLPStack(torch.autograd.Function):
                                   torch.rsqrt(bn.running_var.detach() + bn.eps)))
                 zs.append(z)
             Co = zs[-1].shape[1]
-            if pool_k:
-                rows_out = M // pool_k
-                y = torch.empty((rows_out, Co), **f32)
-                argk = torch.empty((rows_out, Co), dtype=torch.uint8, device=dev)
+            argk2, k2 = None, 0
+            if pool_k > 255:
+                # the winning row of a group is recorded in 8 bits: pool in two stages, k1 <= 255 rows per sub-group
+                # (with the BatchNorm + ReLU), then the k2 = pool_k / k1 sub-group maxima of each group (already
+                # activated: identity coefficients) -- group_all pools a whole cloud (pointnet2_utils.py:141-158, :200)
+                k1 = max(d for d in range(1, 256) if pool_k % d == 0)
+                k2 = pool_k // k1
+                if k1 == 1 or k2 > 255:
+                    raise NotImplementedError("max-pool over %d rows: no two-stage split with both factors <= 255" % pool_k)
+                y1 = torch.empty((M // k1, Co), **f32)
+                argk = torch.empty((M // k1, Co), dtype=torch.uint8, device=dev)
+                rc = lib.pn2_bn_relu_out(_ptr(zs[-1]), M // k1, Co, k1, _ptr(coefs[-1][0]), _ptr(coefs[-1][1]), _ptr(y1),
+                                         _ptr(argk), _stream(dev))
+                _lib.check(rc, "pn2_bn_relu_out")
+                y = torch.empty((M // pool_k, Co), **f32)
+                argk2 = torch.empty((M // pool_k, Co), dtype=torch.uint8, device=dev)
+                one, zero = torch.ones(Co, **f32), torch.zeros(Co, **f32)
+                rc = lib.pn2_bn_relu_out(_ptr(y1), M // pool_k, Co, k2, _ptr(one), _ptr(zero), _ptr(y), _ptr(argk2), _stream(dev))
+                _lib.check(rc, "pn2_bn_relu_out")
+                pool_k = k1
             else:
-                rows_out = M
-                y = torch.empty((M, Co), **f32)
-                argk = None
-            rc = lib.pn2_bn_relu_out(_ptr(zs[-1]), rows_out, Co, pool_k, _ptr(coefs[-1][0]), _ptr(coefs[-1][1]), _ptr(y),
-                                     _ptr(argk), _stream(dev))
-            _lib.check(rc, "pn2_bn_relu_out")
+                if pool_k:
+                    rows_out = M // pool_k
+                    y = torch.empty((rows_out, Co), **f32)
+                    argk = torch.empty((rows_out, Co), dtype=torch.uint8, device=dev)
+                else:
+                    rows_out = M
+                    y = torch.empty((M, Co), **f32)
+                    argk = None
+                rc = lib.pn2_bn_relu_out(_ptr(zs[-1]), rows_out, Co, pool_k, _ptr(coefs[-1][0]), _ptr(coefs[-1][1]), _ptr(y),
+                                         _ptr(argk), _stream(dev))
+                _lib.check(rc, "pn2_bn_relu_out")
         ctx.training = training
         ctx.pool_k = pool_k
+        ctx.argk2, ctx.k2 = argk2, k2
         ctx.L = L
         ctx.has_x2 = x2 is not None
         ctx.argk = argk
@@ -179,6 +201,11 @@ class _MLPStack(torch.autograd.Function):
         K2 = 0 if x2 is None else x2.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
         gy = gy.to(torch.float32).contiguous()
+        if ctx.k2:
+            # second pooling stage: route the pooled gradient to the winning sub-group of each group (small tensors)
+            g1 = torch.zeros((gy.shape[0], ctx.k2, gy.shape[1]), **f32)
+            g1.scatter_(1, ctx.argk2.to(torch.int64).unsqueeze(1), gy.unsqueeze(1))
+            gy = g1.reshape(gy.shape[0] * ctx.k2, gy.shape[1])
         grads = [None] * (4 * L)
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if (_DW_SIDE or M <= _DW_SIDE_MAX_ROWS) else None

@@ -111,10 +111,7 @@ _TORCH_MLP = os.environ.get("PN2_TORCH_MLP", "0") == "1"
 def _mlp(x1, x2, convs, bns, pool_k=0):
     """[rows, K1] | [rows, K2] -> [rows(/pool_k), Cout] through the fused HIP stack.  x1 may carry
     zero pad columns beyond the first conv's input width (see ops.ball_query_group pad_to)."""
-    if _TORCH_MLP or pool_k > 255:
-        # pool_k > 255 only happens with group_all=True (pooling over every point of the cloud, not used
-        # by pointnet2_sem_seg): the fused stack records the arg-max in 8 bits, so that case runs the
-        # conv/BN/ReLU layers through torch (rocBLAS / ATen) on the HIP device
+    if _TORCH_MLP:
         x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
         y = _pointwise_mlp(x[:, :convs[0].weight.shape[1]], convs, bns)
         return y.reshape(-1, pool_k, y.shape[-1]).max(dim=1)[0] if pool_k else y

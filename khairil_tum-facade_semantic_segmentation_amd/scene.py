@@ -167,28 +167,49 @@ class VotePool:
                                   _stream(dev))
         _lib.check(rc, "pn2_add_vote")
 
+    def all_reduce(self, group=None):
+        """Sum the pools of all ranks (one collective per scene): every rank voted on its own
+        sub-batches of the scene, integer votes add exactly in any order.  No-op without a process group."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.pool, op=dist.ReduceOp.SUM, group=group)
+        return self
+
     def labels(self):
         """np.argmax(vote_label_pool, 1) of localfunctions.py:405 (first maximum wins)."""
         return self.torch.argmax(self.pool, dim=1)
 
 
+def shard_batches(num_blocks, batch_size, rank=0, world=1):
+    """Start offsets of the sub-batches (localfunctions.py:386-390 walks range(s_batch_num)) this rank runs when a
+    scene is sharded over `world` ranks: sub-batch i goes to rank i % world."""
+    return list(range(0, num_blocks, batch_size))[rank::world]
+
+
 def infer_scene(model, data_room, index_room, sample_weight, num_points, num_classes, batch_size=32, num_votes=1,
-                retile=None):
+                retile=None, group=None):
     """Whole-scene voting inference (localfunctions.py:375-405): run the network over the scene's
     blocks in sub-batches, vote on the device, return the per-point predicted label tensor.
     `retile`, if given, is called before every vote round after the first to re-draw the blocks
-    (the reference re-tiles per vote, :377)."""
+    (the reference re-tiles per vote, :377; with several ranks it must return the same tiling on every rank).
+    Under torch.distributed (one process per GPU) the sub-batches of the scene are sharded over the ranks and the
+    int32 vote pools are summed with ONE all-reduce per scene (RCCL over xGMI when the backend is "nccl"); every
+    rank returns the full label tensor."""
     import torch
+    import torch.distributed as dist
     dev = next(model.parameters()).device
     votes = VotePool(num_points, num_classes, dev)
     model.eval()
+    rank, world = 0, 1
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
     with torch.no_grad():
         for v in range(num_votes):
             if v > 0 and retile is not None:
                 data_room, _, sample_weight, index_room = retile()
-            for s in range(0, data_room.shape[0], batch_size):
+            for s in shard_batches(data_room.shape[0], batch_size, rank, world):
                 x = torch.as_tensor(data_room[s:s + batch_size], dtype=torch.float32, device=dev).transpose(2, 1)
                 logp, _ = model(x)
                 votes.add(logp=logp, point_idx=torch.as_tensor(index_room[s:s + batch_size], device=dev),
                           weight=torch.as_tensor(sample_weight[s:s + batch_size], dtype=torch.float32, device=dev))
-    return votes.labels()
+    return votes.all_reduce(group).labels()

@@ -226,12 +226,18 @@ def state_shapes(num_classes=18, num_extra_features=3):
 class OracleNet:
     """Functional torch-CPU restatement; parameters live in `self.sd` (name -> tensor)."""
 
-    def __init__(self, state, bn_momentum=0.1, dropout_p=0.5):
+    def __init__(self, state, bn_momentum=0.1, dropout_p=0.5, dtype=None):
+        """dtype=torch.float64: the same network evaluated in double precision on the SAME fp32 geometry (FPS /
+        ball-query / 3-NN indices and interpolation weights are computed from the fp32 coordinates as always): the
+        yardstick for how far any fp32 evaluation order may sit from the exact gradients."""
         import torch
         self.torch = torch
+        self.dtype = dtype or torch.float32
         self.sd = {}
         for k, v in state.items():
             t = torch.as_tensor(np.asarray(v)).clone()
+            if t.is_floating_point():
+                t = t.to(self.dtype)
             if t.is_floating_point() and not k.endswith(("running_mean", "running_var")):
                 t.requires_grad_(True)
             self.sd[k] = t
@@ -272,7 +278,7 @@ class OracleNet:
         self.taps[name + ".ball_idx"] = idx
         tidx = torch.from_numpy(idx)
         bsel = torch.arange(xyz.shape[0]).view(-1, 1, 1)
-        new_xyz = torch.from_numpy(new_xyz_np)
+        new_xyz = torch.from_numpy(new_xyz_np).to(self.dtype)
         g_xyz = xyz[bsel, tidx] - new_xyz.unsqueeze(2)
         grouped = torch.cat([g_xyz, points[bsel, tidx]], dim=-1)          # [B,S,K,3+D]
         x = grouped.permute(0, 3, 2, 1)                                   # [B,C,K,S]
@@ -288,7 +294,7 @@ class OracleNet:
         idx3, _, w3 = three_nn(xyz1.detach().numpy(), xyz2.detach().numpy())
         self.taps[name + ".nn_idx"] = idx3
         self.taps[name + ".nn_weight"] = w3
-        tidx, tw = torch.from_numpy(idx3), torch.from_numpy(w3)
+        tidx, tw = torch.from_numpy(idx3), torch.from_numpy(w3).to(self.dtype)
         bsel = torch.arange(xyz1.shape[0]).view(-1, 1, 1)
         interp = (points2[bsel, tidx] * tw.unsqueeze(-1)).sum(dim=2)      # [B,N,D2]
         x = interp if points1 is None else torch.cat([points1, interp], dim=-1)
@@ -302,7 +308,7 @@ class OracleNet:
         fps_starts = 4 arrays [B].  Returns log-probs [B,N,classes] and l4 feats [B,512,16]."""
         torch = self.torch
         F = torch.nn.functional
-        x = torch.as_tensor(blocks, dtype=torch.float32)
+        x = torch.as_tensor(blocks, dtype=self.dtype)
         pts = x.permute(0, 2, 1).contiguous()                              # [B,N,C]
         xyzs, feats = [pts[:, :, :3].contiguous()], [pts]
         for (name, npoint, radius, nsample, mlp), st in zip(SA_CFG, fps_starts):
@@ -328,7 +334,7 @@ class OracleNet:
         torch = self.torch
         F = torch.nn.functional
         t = torch.as_tensor(target, dtype=torch.int64).reshape(-1)
-        w = None if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+        w = None if weight is None else torch.as_tensor(weight, dtype=self.dtype)
         return F.nll_loss(logp.reshape(-1, logp.shape[-1]), t, weight=w)
 
     def train_step(self, blocks, target, fps_starts, optimizer, weight=None):

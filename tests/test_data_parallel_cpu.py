@@ -80,3 +80,42 @@ def test_rotate_z_matches_reference_formula():
         want[k, :, :3] = pc[k, :, :3].reshape(-1, 3) @ R
     got = rotate_z_(torch.from_numpy(pc).permute(0, 2, 1).contiguous(), torch.from_numpy(ang).float())
     assert np.abs(got.permute(0, 2, 1).numpy() - want).max() < 1e-5
+
+
+def _vote_worker(rank, world, port, out):
+    """Whole-scene inference sharded over ranks: each rank votes on its sub-batches, ONE all-reduce of
+    the int32 pool per scene.  The pool arithmetic on CPU is the oracle's add_vote (test infrastructure: the product's
+    add() is the HIP kernel); what is under test is the sharding and the collective of scene.VotePool."""
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khairil_tum_facade_semantic_segmentation_amd import scene
+    from oracle import scene_oracle
+    rs = np.random.RandomState(5)                          # identical scene on every rank
+    blocks, bp, P, C, bs = 11, 64, 300, 5, 3
+    point_idx = rs.randint(0, P, size=(blocks, bp))
+    pred = rs.randint(0, C, size=(blocks, bp))
+    weight = rs.choice([0.0, 1.0, 2.5, np.inf], size=(blocks, bp))
+    pool = scene.VotePool(P, C, torch.device("cpu"))
+    mine = scene.shard_batches(blocks, bs, rank, world)
+    local = np.zeros((P, C), np.int64)
+    for s in mine:
+        scene_oracle.add_vote(local, point_idx[s:s + bs], pred[s:s + bs], weight[s:s + bs])
+    pool.pool += torch.from_numpy(local).to(torch.int32)
+    pool.all_reduce()
+    want = np.zeros((P, C), np.int64)
+    scene_oracle.add_vote(want, point_idx, pred, weight)
+    covered = sorted(s for r in range(world) for s in scene.shard_batches(blocks, bs, r, world))
+    ok = covered == list(range(0, blocks, bs)) and np.array_equal(pool.pool.numpy(), want)
+    ok = ok and np.array_equal(pool.labels().numpy(), want.argmax(1))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_scene_vote_pool_sharded_world2():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_vote_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Gradient distance of the HIP train step from the oracle network in fp32 and fp64 (same fp32 geometry):
+    python tools/gradcheck.py [B] [kind]      (GPU box)"""
+import os
+import sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+from khairil_tum_facade_semantic_segmentation_amd import ops, synth
+from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_utils as U
+from oracle import pn2_oracle as orc
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+kind = sys.argv[2] if len(sys.argv) > 2 else "cube"
+K, C = 18, 9
+blocks, labels, starts, cw = synth.draw_case(synth.BENCH_SEED, B, 4096, C, kind, K)
+filled = synth.fill_state_dict(orc.state_shapes(K, C - 6))
+model = M.get_model(K, C - 6)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+model = model.cuda().train()
+model.drop1.p = 0.0
+with U.fps_starts(starts):
+    pred, tf = model(torch.from_numpy(blocks).cuda().permute(0, 2, 1))
+loss = M.get_loss()(pred.contiguous().view(-1, K), torch.from_numpy(labels).cuda().view(-1), tf, torch.from_numpy(cw).cuda())
+loss.backward()
+grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+res = {}
+for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
+    net = orc.OracleNet(filled, dropout_p=0.0, dtype=dt)
+    net.training = True
+    logp, _ = net.forward(blocks.transpose(0, 2, 1), starts)
+    ol = net.loss(logp, labels, cw)
+    ol.backward()
+    res[name] = (float(ol.detach()), {k: p.grad.numpy().astype(np.float64) for k, p in net.named_parameters()})
+print("loss hip %.7f fp32 %.7f fp64 %.7f" % (float(loss), res["fp32"][0], res["fp64"][0]))
+print("%-28s %10s %10s %10s | relative L2: %8s %8s" % ("tensor", "hip-fp64", "hip-fp32", "fp32-fp64", "hip-fp64", "fp32-fp64"))
+worst = [0.0] * 5
+for k in grads:
+    if ("mlp_convs" in k or k == "conv1.bias") and k.endswith(".bias"):
+        continue                                     # a conv bias under train-mode BatchNorm: exact gradient 0
+    r64, r32 = res["fp64"][1][k], res["fp32"][1][k]
+    s = np.abs(r64).max() + 1e-12
+    n = np.linalg.norm(r64) + 1e-12
+    row = (100 * np.abs(grads[k] - r64).max() / s, 100 * np.abs(grads[k] - r32).max() / s, 100 * np.abs(r32 - r64).max() / s,
+           100 * np.linalg.norm(grads[k] - r64) / n, 100 * np.linalg.norm(r32 - r64) / n)
+    worst = [max(a, b) for a, b in zip(worst, row)]
+    print("%-28s %9.3f%% %9.3f%% %9.3f%% | %20.3f%% %7.3f%%" % ((k,) + row))
+print("%-28s %9.3f%% %9.3f%% %9.3f%% | %20.3f%% %7.3f%%" % (("WORST",) + tuple(worst)))

@@ -79,8 +79,14 @@ def bench_nn():
         idx3, w3 = ops.three_nn(x1, x2)
         t2 = timeit(lambda: ops.three_interpolate(p2, idx3, w3))
         g = torch.randn(16, N, D, device="cuda")
-        out = ops.three_interpolate(p2.requires_grad_(True), idx3, w3)
-        t3 = timeit(lambda: torch.autograd.grad(out, p2, g, retain_graph=True), reps=5)
+        p2.requires_grad_(True)
+        # forward AND backward inside the captured region.  (Round 1 built `out` outside and differentiated it inside
+        # the capture: the autograd engine then runs the backward on the FORWARD's stream -- the legacy default
+        # stream -- from its worker thread while another stream is in global-mode capture, which HIP forbids
+        # (hipErrorStreamCaptureImplicit, capture invalidated; with an allocator miss also a hipMalloc during capture).
+        # That is what dumped core in profiles/r01/kbench_v0.log)
+        t3 = timeit(lambda: torch.autograd.grad(ops.three_interpolate(p2, idx3, w3), p2, g), reps=5) - t2
+        p2.requires_grad_(False)
         print("three_nn N=%d S=%d: %.1f us | interpolate D=%d: %.1f us | backward %.1f us" % (N, S, t, D, t2, t3))
 
 

@@ -1,20 +1,36 @@
 #!/usr/bin/env python3
-"""Runs the SA1 query_ball_point+group kernel a few times (target of rocprofv3 runs)."""
+"""Runs the SA1 query_ball_point+group path a few times (target of rocprofv3 runs):
+    python tools/run_ball.py [cube|facade] [reps] [planned|selfcontained]
+planned (default): FPS-with-plan once, rows packed once, then `reps` launches of pn2_ball_query_group_planned."""
 import os
 import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
-from khairil_tum_facade_semantic_segmentation_amd import ops, synth
+from khairil_tum_facade_semantic_segmentation_amd import _lib, ops, synth
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "cube"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-grouped = (sys.argv[3] != "idx") if len(sys.argv) > 3 else True
+mode = sys.argv[3] if len(sys.argv) > 3 else "planned"
 blocks, _, starts, _ = synth.draw_case(synth.BENCH_SEED, 16, 4096, 9, kind)
 pts = torch.from_numpy(blocks).cuda()
 xyz = pts[:, :, :3].contiguous()
-_, new_xyz = ops.farthest_point_sample_with_xyz(xyz, 1024, torch.from_numpy(starts[0]).cuda())
-for _ in range(reps):
-    ops._ball_query_group_raw(0.1, 32, xyz, new_xyz, pts if grouped else None, grouped)
+lib = _lib.load()
+idx = torch.empty((16, 1024, 32), dtype=torch.int64, device="cuda")
+grouped = torch.empty((16, 1024, 32, 12), dtype=torch.float32, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+if mode == "planned":
+    _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, 1024, 0.1, 9, torch.from_numpy(starts[0]).cuda())
+    plan.pack_rows(xyz, pts)
+    for _ in range(reps):
+        rc = lib.pn2_ball_query_group_planned(0.1, 32, plan.buf.data_ptr(), xyz.data_ptr(), new_xyz.data_ptr(), pts.data_ptr(), 16, 4096,
+                                              1024, 9, idx.data_ptr(), grouped.data_ptr(), 0, None, st)
+        assert rc == 0
+else:
+    _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, 1024, torch.from_numpy(starts[0]).cuda())
+    for _ in range(reps):
+        rc = lib.pn2_ball_query_group(0.1, 32, xyz.data_ptr(), new_xyz.data_ptr(), pts.data_ptr(), 16, 4096, 1024, 9, idx.data_ptr(),
+                                      grouped.data_ptr(), 0, None, st)
+        assert rc == 0
 torch.cuda.synchronize()
 print("done")
