@@ -92,6 +92,56 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
+def run_control(args, dev):
+    """BASELINE configs[4]: pointnet_sem_seg (plain PointNet, no set abstraction) on the same 16 x 4096 x 9 blocks --
+    the pointwise-MLP-only control: fwd + backward + Adam per step, priced against the fp32 MFMA peak (its GEMMs)
+    and against the HBM roof (its activation traffic)."""
+    from khairil_tum_facade_semantic_segmentation_amd import synth
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet_sem_seg as P
+    blocks, labels, _, _ = synth.draw_case(synth.BENCH_SEED, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind, NUM_CLASSES)
+    x = torch.from_numpy(np.ascontiguousarray(blocks.transpose(0, 2, 1))).to(dev)
+    y = torch.from_numpy(labels).to(dev).view(-1)
+    model = P.get_model(NUM_CLASSES, CHANNELS - 6)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model = model.to(dev).train()
+    crit = P.get_loss()
+    cw = torch.ones(NUM_CLASSES, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logp, tf = model(x)
+        loss = crit(logp.reshape(-1, NUM_CLASSES), y, tf, cw)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).item()
+    pts = PER_GPU_BATCH * BLOCK_POINTS * args.steps
+    macs = P.macs_per_point(CHANNELS, NUM_CLASSES)
+    flops = 3 * 2 * macs * pts                                       # forward + two backward products per layer
+    # activation traffic: every layer's raw output (fp32) is written once, read by the next layer and by the backward,
+    # and its gradient written and read once: 5 passes over sum(Co) floats per point
+    widths = (64 + 128 + 1024) * 2 + 64 + 128 + 1024 + 512 + 256 + 128 + NUM_CLASSES
+    act_bytes = 5 * 4 * widths * pts
+    return {"metric": "points/sec fwd+bwd, 4096-pt blocks, pointnet_sem_seg (pointwise-MLP control)", "value": pts / dt,
+            "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "pointnet_sem_seg fwd+bwd+Adam, batch=16x4096x9 synthetic %s blocks (BASELINE configs[4])" % args.kind,
+                       "global_batch": PER_GPU_BATCH, "points_per_block": BLOCK_POINTS, "parallelism": "dp1"},
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": flops / dt / 1e12 / 157.3, "traffic": None, "macs_per_point": macs,
+                         "activation_gbs": act_bytes / dt / 1e9, "activation_frac_of_hbm": act_bytes / dt / 1e9 / HBM_PEAK_GBS}}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run as
     fresh child processes -- this parent has not touched the GPU -- and pass their output and exit code through."""
@@ -111,6 +161,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--kind", default="cube", choices=("cube", "facade"))
+    ap.add_argument("--model", default="pointnet2_sem_seg", choices=("pointnet2_sem_seg", "pointnet_sem_seg"),
+                    help="pointnet_sem_seg = the plain-PointNet control of BASELINE configs[4] (pointwise MLPs only, one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -142,6 +194,12 @@ def main():
     from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
     from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer
     _lib.load()
+    if args.model == "pointnet_sem_seg":
+        if rank == 0:
+            print(json.dumps(run_control(args, dev)), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     # synthetic blocks of this rank (weak scaling: 16 blocks per GPU), resident in HBM
     blocks, labels, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind,
