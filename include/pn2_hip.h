@@ -300,6 +300,19 @@ int pn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 int pn2_add_vote(const float *logp, const int64_t *pred_label, const int64_t *point_idx, const float *weight,
                  long long M, int C, long long P, int32_t *vote_pool, int32_t *err_count, pn2_stream_t stream);
 
+/* ---- loop glue on the device --------------------------------------------------------
+ * pn2_input_blocks: the input preparation of a training step (localfunctions.py:205-209) in one pass: per block b
+ * the xyz columns are rotated about the up axis by angles[b] radians (provider.rotate_point_cloud_z,
+ * provider.py:66-84; angles NULL = no rotation) and the batch is laid out for the network.  in: [B][C][N] when
+ * channel_first != 0 (what the loop hands to the classifier) else [B][N][C]; pts [B][N][C] channel-last rows;
+ * xyz (nullable) [B][N][3].  C >= 3.
+ * pn2_seg_metrics: accuracy / IoU bookkeeping of a batch (localfunctions.py:214, 220-223, 271-283) added to
+ * int64 device counters [2 + 3*C]: [0] correct, [1] seen, [2+c] label == c, [2+C+c] pred == c && label == c,
+ * [2+2C+c] pred == c || label == c; pred = arg-max of the row of logp [M][C] (first maximum wins).  C <= 64. */
+int pn2_input_blocks(const float *in, int channel_first, int B, int N, int C, const float *angles, float *pts, float *xyz,
+                     pn2_stream_t stream);
+int pn2_seg_metrics(const float *logp, const int64_t *target, long long M, int C, long long *counters, pn2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,13 +41,19 @@ class get_model(nn.Module):
         self.drop1 = nn.Dropout(0.5)
         self.conv2 = nn.Conv1d(128, num_classes, 1)
 
-    def compute_geometry(self, xyz):
+    def prepare_input(self, xyz, angles=None):
+        """The step's input preparation as one kernel (ops.input_blocks): xyz [B, C, N] channel-first -> (rows [B,N,C],
+        coordinates [B,N,3]), with the per-block rotation about the up axis of the reference loop (localfunctions.py:206)
+        when `angles` [B] is given.  Pass the result as `prepared=` to compute_geometry() / forward()."""
+        return ops.input_blocks(xyz, True, angles)
+
+    def compute_geometry(self, xyz=None, prepared=None):
         """Everything in the forward pass that depends on the input coordinates only: the FPS /
         ball-query pyramid of the four SA levels and the 3-NN tables of the four FP levels
         (SURVEY.md 3.3).  Returns a flat list of tensors that forward(geometry=...) consumes; it
         can be computed ahead of time (another stream, one batch early) because no learned
         quantity feeds it."""
-        cur = xyz.permute(0, 2, 1)[:, :, :3].contiguous()
+        cur = prepared[1] if prepared is not None else xyz.permute(0, 2, 1)[:, :, :3].contiguous()
         levels = [cur]
         out, inv = [], []
         for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
@@ -72,10 +78,15 @@ class get_model(nn.Module):
             return ()
         return ((geometry[16 + 2 * slot], geometry[17 + 2 * slot]),)
 
-    def forward(self, xyz, geometry=None):
-        """xyz [B, 3+3+extra, N] -> (log_softmax [B,N,classes], l4_points [B,512,16])."""
-        pts = xyz.permute(0, 2, 1).contiguous()          # [B,N,C]
-        geo = [pts[:, :, :3].contiguous()]
+    def forward(self, xyz, geometry=None, prepared=None):
+        """xyz [B, 3+3+extra, N] -> (log_softmax [B,N,classes], l4_points [B,512,16]).  prepared = prepare_input(xyz,
+        angles): the (rotated) rows and coordinates to run on instead of xyz itself."""
+        if prepared is not None:
+            pts, xyz3 = prepared
+        else:
+            pts = xyz.permute(0, 2, 1).contiguous()      # [B,N,C]
+            xyz3 = pts[:, :, :3].contiguous()
+        geo = [xyz3]
         feat = [pts]
         for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
             pre = None if geometry is None else (geometry[2 * i], geometry[2 * i + 1]) + self._inverse(geometry, i)

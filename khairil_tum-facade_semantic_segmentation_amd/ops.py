@@ -467,3 +467,60 @@ def three_interpolate(points2, idx3, weight3, inv=None):
     inv = invert_index(idx3, S): the backward then gathers instead of scatter-adding."""
     io, ie = inv if inv is not None else (None, None)
     return _ThreeInterpolate.apply(points2.to(torch.float32).contiguous(), _i64c(idx3), _f32c(weight3), io, ie)
+
+
+# ---------------------------------------------------------------------------------- loop glue (SURVEY.md 8f row 4)
+def input_blocks(x, channel_first=True, angles=None):
+    """Input preparation of a training step on the device (localfunctions.py:205-209): x [B,C,N] (channel_first) or
+    [B,N,C]; angles [B] radians (None: no rotation) rotate the xyz columns of each block about the up axis
+    (provider.rotate_point_cloud_z).  -> (pts [B,N,C] channel-last rows, xyz [B,N,3])."""
+    dev = _dev(x, angles)
+    lib = _lib.load()
+    x = _f32c(x)
+    if channel_first:
+        B, C, N = x.shape
+    else:
+        B, N, C = x.shape
+    if angles is not None:
+        angles = _f32c(angles)
+        if angles.shape != (B,):
+            raise ValueError("angles must be [B]")
+    pts = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_input_blocks(_ptr(x), 1 if channel_first else 0, B, N, C, _ptr(angles), _ptr(pts), _ptr(xyz), _stream(dev))
+    _lib.check(rc, "pn2_input_blocks")
+    return pts, xyz
+
+
+class SegMetrics:
+    """Accuracy / IoU counters of the reference loops (localfunctions.py:214, 220-223, 271-289) kept on the device:
+    add() enqueues one kernel per batch (no host synchronisation, hipGraph-capture safe), read() fetches the int64
+    counters once -- per epoch -- and derives what the loops log."""
+
+    def __init__(self, num_classes, device):
+        self.C = int(num_classes)
+        self.counters = torch.zeros(2 + 3 * self.C, dtype=torch.int64, device=device)
+
+    def reset(self):
+        self.counters.zero_()
+
+    def add(self, logp, target):
+        dev = _dev(logp, target, self.counters)
+        lib = _lib.load()
+        logp = _f32c(logp).reshape(-1, self.C)
+        target = _i64c(target).reshape(-1)
+        if target.numel() != logp.shape[0]:
+            raise ValueError("logp rows and targets differ")
+        with torch.cuda.device(dev):
+            rc = lib.pn2_seg_metrics(_ptr(logp), _ptr(target), logp.shape[0], self.C, _ptr(self.counters), _stream(dev))
+        _lib.check(rc, "pn2_seg_metrics")
+
+    def read(self):
+        c = self.counters.cpu().numpy().astype("float64")
+        C = self.C
+        seen_c, correct_c, union_c = c[2:2 + C], c[2 + C:2 + 2 * C], c[2 + 2 * C:2 + 3 * C]
+        return {"correct": int(c[0]), "seen": int(c[1]), "accuracy": c[0] / max(c[1], 1.0),
+                "class_seen": seen_c, "class_correct": correct_c, "class_union": union_c,
+                "mIoU": float((correct_c / (union_c + 1e-6)).mean()),                      # localfunctions.py:283
+                "avg_class_acc": float((correct_c / (seen_c + 1e-6)).mean())}              # :287-288

@@ -120,7 +120,11 @@ class SemSegTrainer:
     busy as the GPU."""
 
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, class_weight=None, group=None, graphs=False,
-                 graph_warmup=3, prefetch_geometry=False):
+                 graph_warmup=3, prefetch_geometry=False, augment=False, metrics=False):
+        """augment: rotate every block about the up axis by a fresh random angle per step, on the device, inside the
+        input-preparation kernel (the reference does it on the host between two copies, localfunctions.py:205-208).
+        metrics: accumulate the loop's accuracy / IoU counters on the device (self.metrics.read() once per epoch
+        replaces the per-step .cpu() of localfunctions.py:214-223)."""
         self.model = model
         self.group = group
         self.grads = FlatGradients(model)
@@ -138,6 +142,12 @@ class SemSegTrainer:
         # its coordinates only) is computed on a side stream while this batch's MLP work runs:
         # FPS is a latency-bound chain that occupies 16 of 256 CUs.
         self.prefetch = bool(prefetch_geometry) and on_gpu and hasattr(model, "compute_geometry")
+        self.augment = bool(augment) and on_gpu and hasattr(model, "prepare_input")
+        self.metrics = None
+        if metrics and on_gpu:
+            from .ops import SegMetrics
+            ncls = model.conv2.out_channels if hasattr(model, "conv2") else int(metrics)
+            self.metrics = SegMetrics(ncls, next(model.parameters()).device)
         self._side = torch.cuda.Stream() if self.prefetch else None
         self._geo_next = None            # pyramid computed for the coming step
         self._geo_next_src = None        # identity (data_ptr, version, shape) of the batch it was computed from
@@ -210,13 +220,24 @@ class SemSegTrainer:
         return self._world() > 1 or (os.environ.get("PN2_FORCE_DP_PATH", "0") == "1"
                                      and dist.is_available() and dist.is_initialized())
 
+    def _draw_angles(self, blocks_cf):
+        return torch.rand(blocks_cf.shape[0], device=blocks_cf.device) * 6.283185307179586     # provider.py:76
+
+    def _geometry_of(self, blocks_cf):
+        """The pyramid of a batch; with augmentation the rotated input it was computed on travels with it (last two
+        entries: rows [B,N,C], coordinates [B,N,3]) so that the forward one step later runs on the same rotation."""
+        with torch.no_grad():
+            if not self.augment:
+                return self.model.compute_geometry(blocks_cf)
+            prepared = self.model.prepare_input(blocks_cf, self._draw_angles(blocks_cf))
+            return self.model.compute_geometry(prepared=prepared) + [prepared[0], prepared[1]]
+
     def _launch_prefetch(self, next_blocks_cf):
         """Enqueue the geometry pyramid of `next_blocks_cf` on the side stream."""
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            with torch.no_grad():
-                geo = self.model.compute_geometry(next_blocks_cf)
+            geo = self._geometry_of(next_blocks_cf)
         return geo
 
     def _pack_geometry(self, geo):
@@ -231,9 +252,18 @@ class SemSegTrainer:
 
     def _forward_backward(self, blocks_cf, target, geometry=None):
         self.grads.zero()
-        pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
+        if self.augment:
+            if geometry is not None:
+                prepared, geometry = (geometry[-2], geometry[-1]), geometry[:-2]
+            else:
+                prepared = self.model.prepare_input(blocks_cf, self._draw_angles(blocks_cf))
+            pred, _ = self.model(blocks_cf, geometry=geometry, prepared=prepared)
+        else:
+            pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
         loss = self.criterion(pred.reshape(-1, pred.shape[-1]), target.reshape(-1), None, self.class_weight)
         loss.backward()
+        if self.metrics is not None:
+            self.metrics.add(pred.detach(), target)      # one kernel, no host sync (localfunctions.py:220-223)
         return loss.detach()
 
     def _optimizer_step(self, grad_scale=1.0):
@@ -279,8 +309,7 @@ class SemSegTrainer:
             # `cur` while the optimizer runs on the main stream (so no copy sits on the critical path)
             self._static_next_x = blocks_cf.clone()
             torch.cuda.current_stream().wait_stream(self._side)
-            with torch.no_grad():
-                first = self.model.compute_geometry(self._static_x)
+            first = self._geometry_of(self._static_x)
             # all pyramid tensors live in ONE byte buffer (16-byte aligned segments), so the hand-over after
             # backward is a single copy instead of one small copy kernel per tensor (24 x 4 us on the step's tail)
             self._geo_pads, off = [], 0
@@ -353,8 +382,7 @@ class SemSegTrainer:
             if self._geo_next_src != self._identity(blocks_cf):
                 # the pyramid in `cur` was computed for another batch (the caller did not announce this one as
                 # next_blocks_cf): compute this batch's pyramid now, on the main stream, before the replay reads it
-                with torch.no_grad():
-                    self._geo_flat.copy_(self._pack_geometry(self.model.compute_geometry(self._static_x)))
+                self._geo_flat.copy_(self._pack_geometry(self._geometry_of(self._static_x)))
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._static_next_x.copy_(nxt)
             self._geo_next_src = self._identity(nxt)
