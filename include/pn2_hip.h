@@ -309,6 +309,20 @@ int pn2_add_vote(const float *logp, const int64_t *pred_label, const int64_t *po
  * pn2_seg_metrics: accuracy / IoU bookkeeping of a batch (localfunctions.py:214, 220-223, 271-283) added to
  * int64 device counters [2 + 3*C]: [0] correct, [1] seen, [2+c] label == c, [2+C+c] pred == c && label == c,
  * [2+2C+c] pred == c || label == c; pred = arg-max of the row of logp [M][C] (first maximum wins).  C <= 64. */
+/* pn2_sample_blocks: TrainCustomDataset.__getitem__ (sem_seg_training.py:200-259) for B blocks of one scene that
+ * lives on the device: xyz [P][3] double; order [P] / cell_start [nx*ny+1] = the points bucketed into a 2-D grid of
+ * `cell`-sized cells from (x0, y0), row-major, ascending index inside a cell; extra [E][P] (nullable) the extra
+ * feature columns already scaled; labels [P]; coord_max [3] HOST doubles (room_coord_max).  Per block: a random
+ * point as centre, re-drawn until the block_size column around it holds more than min_points points; num_point of
+ * them, a uniformly random subset in random order (or, when fewer, uniform draws with replacement); feats
+ * [B][num_point][6+E] = [x - cx, y - cy, z, xyz / coord_max, extra], out_labels [B][num_point], info [B][4] =
+ * (centre index, points in the window, attempts, 1 if no such column was found in 256 attempts: zero block);
+ * sel_idx (nullable) [B][num_point] the chosen point indices.
+ * All randomness derives from `seed`: same seed, same blocks.  num_point <= 4096. */
+int pn2_sample_blocks(const double *xyz, const int *order, const int *cell_start, const float *extra,
+                      const long long *labels, double x0, double y0, double cell, int nx, int ny, int P, int E,
+                      double block_size, const double *coord_max, int num_point, int min_points, unsigned long long seed,
+                      int B, float *feats, long long *out_labels, int *info, int *sel_idx, pn2_stream_t stream);
 int pn2_input_blocks(const float *in, int channel_first, int B, int N, int C, const float *angles, float *pts, float *xyz,
                      pn2_stream_t stream);
 int pn2_seg_metrics(const float *logp, const int64_t *target, long long M, int C, long long *counters, pn2_stream_t stream);

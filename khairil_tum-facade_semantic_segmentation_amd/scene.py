@@ -138,6 +138,94 @@ class BlockSampler:
         return out, self.labels[chosen]
 
 
+class DeviceBlockSampler:
+    """BlockSampler with the scene resident on the device: the grid index is built once on the
+    host (GridIndex) and uploaded; sample(B, seed) draws B training blocks with one kernel launch
+    (csrc/pn2_sampler.hip; same block semantics as TrainCustomDataset.__getitem__, randomness from a counter-based
+    hash of the seed), sample_exact() replays the reference's numpy random stream -- host-drawn centre indices and
+    choice() positions -- and returns float64 features that equal the reference's bit for bit."""
+
+    def __init__(self, points, labels, extra=(), feature_name=(), num_point=4096, block_size=1.0, device="cuda"):
+        import torch
+        self.torch = torch
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64)[:, :3])
+        self.P = pts.shape[0]
+        self.num_point, self.block_size = int(num_point), float(block_size)
+        self.coord_max = pts.max(axis=0)
+        gi = GridIndex(pts[:, :2], cell=block_size / 4.0)
+        self.grid = gi
+        dev = torch.device(device)
+        self.dev = dev
+        self.xyz = torch.from_numpy(pts).to(dev)
+        self.order = torch.from_numpy(gi.order.astype(np.int32)).to(dev)
+        self.cell_start = torch.from_numpy(gi.start.astype(np.int32)).to(dev)
+        self.labels = torch.from_numpy(np.asarray(labels).astype(np.int64)).to(dev)
+        self.feature_name = list(feature_name)
+        self.extra_raw = [torch.from_numpy(np.ascontiguousarray(np.asarray(e))).to(dev) for e in extra]
+        cols = []
+        for e, name in zip(extra, self.feature_name):
+            e = np.asarray(e, dtype=np.float64)
+            cols.append((e / 255 if name in ("red", "blue", "green") else e).astype(np.float32))      # :241-243
+        self.E = len(cols)
+        self.extra = torch.from_numpy(np.stack(cols)).to(dev) if cols else None
+
+    def sample(self, B, seed, want_indices=False):
+        """-> feats [B, num_point, 6+E] float32, labels [B, num_point] int64, info [B, 4] int32 (centre index,
+        points in the window, attempts, gave-up flag) [, indices [B, num_point] int32]"""
+        from . import _lib
+        import ctypes
+        torch = self.torch
+        lib = _lib.load()
+        F = 6 + self.E
+        feats = torch.empty((B, self.num_point, F), dtype=torch.float32, device=self.dev)
+        labs = torch.empty((B, self.num_point), dtype=torch.int64, device=self.dev)
+        info = torch.empty((B, 4), dtype=torch.int32, device=self.dev)
+        sel = torch.empty((B, self.num_point), dtype=torch.int32, device=self.dev) if want_indices else None
+        cm = (ctypes.c_double * 3)(*[float(v) for v in self.coord_max])
+        gi = self.grid
+        with torch.cuda.device(self.dev):
+            rc = lib.pn2_sample_blocks(self.xyz.data_ptr(), self.order.data_ptr(), self.cell_start.data_ptr(),
+                                       None if self.extra is None else self.extra.data_ptr(), self.labels.data_ptr(),
+                                       float(gi.origin[0]), float(gi.origin[1]), float(gi.cell), gi.nx, gi.ny, self.P, self.E,
+                                       self.block_size, cm, self.num_point, 1024, int(seed) & (2 ** 64 - 1), B, feats.data_ptr(),
+                                       labs.data_ptr(), info.data_ptr(), None if sel is None else sel.data_ptr(),
+                                       torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(rc, "pn2_sample_blocks")
+        return (feats, labs, info, sel) if want_indices else (feats, labs, info)
+
+    def sample_exact(self, rng=np.random):
+        """One block with the reference's own random stream: rng.choice(P) per attempt (:207), then rng.choice over the
+        window's points (:219-221).  float64 features [num_point, 6+E] and labels, bit-identical to the reference."""
+        torch = self.torch
+        half = self.block_size / 2.0
+        x, y = self.xyz[:, 0], self.xyz[:, 1]
+        while True:
+            ci = int(rng.choice(self.P))
+            c = self.xyz[ci]
+            cx, cy = float(c[0]), float(c[1])
+            mask = (x >= cx - half) & (x <= cx + half) & (y >= cy - half) & (y <= cy + half)
+            idxs = torch.nonzero(mask).squeeze(1)                      # ascending, like np.where
+            if idxs.numel() > 1024:
+                break
+        cnt = int(idxs.numel())
+        pos = rng.choice(cnt, self.num_point, replace=cnt < self.num_point)
+        sel = idxs[torch.from_numpy(np.asarray(pos, dtype=np.int64)).to(self.dev)]
+        sp = self.xyz[sel]
+        out = torch.empty((self.num_point, 6 + self.E), dtype=torch.float64, device=self.dev)
+        cm = torch.from_numpy(self.coord_max).to(self.dev)
+        out[:, 3:6] = sp / cm
+        out[:, 0] = sp[:, 0] - c[0]
+        out[:, 1] = sp[:, 1] - c[1]
+        out[:, 2] = sp[:, 2]
+        # a DEVICE divisor: torch turns `tensor / python_scalar` into a multiplication by the reciprocal on the GPU,
+        # which is not the correctly rounded quotient the reference's numpy division yields
+        c255 = torch.full((1,), 255.0, dtype=torch.float64, device=self.dev)
+        for k, (raw, name) in enumerate(zip(self.extra_raw, self.feature_name)):
+            f = raw[sel].to(torch.float64)
+            out[:, 6 + k] = f / c255 if name in ("red", "blue", "green") else f
+        return out.cpu().numpy(), self.labels[sel].cpu().numpy()
+
+
 class VotePool:
     """vote_label_pool of modelTesting (localfunctions.py:373-403) kept on the device as int32
     [num_points, num_classes]; add() scatters one vote per (point, arg-max class) with the HIP

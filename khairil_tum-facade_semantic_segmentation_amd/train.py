@@ -391,3 +391,41 @@ class SemSegTrainer:
             dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)
             self._g_opt.replay()
         return self._static_loss
+
+
+def epoch_schedule(epoch, learning_rate=1e-3, lr_decay=0.7, step_size=10):
+    """(lr, BatchNorm momentum) of an epoch, localfunctions.py:168-193: lr = max(lr0 * decay^(epoch // step), 1e-5);
+    momentum = max(0.1 * 0.5^(epoch // step), 0.01)."""
+    lr = max(learning_rate * (lr_decay ** (epoch // step_size)), 1e-5)
+    momentum = max(0.1 * (0.5 ** (epoch // step_size)), 0.01)
+    return lr, momentum
+
+
+def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_rate=1e-3, lr_decay=0.7, step_size=10):
+    """One epoch of the reference's training loop (modelTraining, localfunctions.py:184-227) with every per-step piece
+    on the device: blocks drawn by scene.DeviceBlockSampler (one per room; a batch comes from one room, rooms
+    taken in turn), rotate-z inside the input kernel and accuracy counters on the device (construct the trainer with
+    augment=True, metrics=True), the epoch's learning rate and BatchNorm momentum applied graph-safely.  The next
+    batch is drawn before the current one is stepped, so the trainer's geometry prefetch runs on it meanwhile.
+    -> {"loss": mean loss, "accuracy": ..., "lr": ..., "bn_momentum": ...} (one host sync at the end)."""
+    lr, momentum = epoch_schedule(epoch, learning_rate, lr_decay, step_size)
+    trainer.set_lr(lr)
+    trainer.set_bn_momentum(momentum)
+    if trainer.metrics is not None:
+        trainer.metrics.reset()
+
+    def draw(i):
+        sp = samplers[i % len(samplers)]
+        feats, labels, _ = sp.sample(batch_size, seed=(seed * 1000003 + epoch) * 1000003 + i)
+        return feats.permute(0, 2, 1), labels                  # channel-first view, like the loop's points.transpose(2, 1)
+
+    nxt = draw(0)
+    loss_sum = None
+    for i in range(steps):
+        cur, nxt = nxt, draw(i + 1) if i + 1 < steps else None
+        loss = trainer.step(cur[0], cur[1], None if nxt is None else nxt[0])
+        loss_sum = loss.clone() if loss_sum is None else loss_sum + loss
+    out = {"loss": float(loss_sum) / max(steps, 1), "lr": lr, "bn_momentum": momentum}
+    if trainer.metrics is not None:
+        out.update(trainer.metrics.read())
+    return out
