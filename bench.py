@@ -310,6 +310,17 @@ def main():
 
     reps = 50
     k_ms = back_to_back_ms(planned, reps)
+    # the same launch on the other synthetic distribution (dense facade slab: most balls truncated at nsample; sparse
+    # cube: most balls scanned to the end), beside the figure for the distribution the steps were timed on
+    other_kind = "facade" if args.kind == "cube" else "cube"
+    oblocks, _, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, other_kind, NUM_CLASSES)
+    keep = (pts, xyz, new_xyz, plan)
+    pts = torch.from_numpy(oblocks).to(dev)
+    xyz = pts[:, :, :3].contiguous()
+    _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, 1024, 0.1, CHANNELS, start)
+    plan.pack_rows(xyz, pts)
+    k_ms_other = back_to_back_ms(planned, reps)
+    pts, xyz, new_xyz, plan = keep
     # one event pair per launch: includes the launch latency of an idle queue
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
@@ -362,6 +373,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": k_ms,
                          "kernel_ms_single_launch": k_ms_single,
+                         "other_distribution": {"kind": other_kind, "kernel_ms": k_ms_other,
+                                                "frac": algo / (k_ms_other * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "plan_standalone_ms": prod_ms, "plan_with_fps_ms": fps_plan_ms - fps_plain_ms,
                          "fps_kernel_ms": fps_plain_ms, "self_contained_entry_ms": self_ms,
                          "frac_with_standalone_plan": algo / ((k_ms + prod_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -74,30 +74,44 @@ def read_las(path):
     return LasData(x, y, z, cls, red, green, blue, hdr)
 
 
-def write_las(path, xyz, classification, rgb=None, scale=0.001, version=(1, 2)):
-    """Write points as format 2/3-free minimal LAS: format 2 (with RGB) or 0; for tests and for
-    exporting synthetic scenes."""
+def write_las(path, xyz, classification, rgb=None, scale=0.001, version=(1, 2), point_format=None, extra_bytes=0):
+    """Write points as minimal LAS: by default format 2 (with RGB) or 0 under a LAS 1.2 header; point_format
+    6 / 7 / 8 writes the LAS 1.4 layouts (375-byte header, 64-bit point count, 8-bit classification at byte 16,
+    RGB at byte 30 for 7 and 8).  extra_bytes appends that many user bytes to every record (filled with a pattern),
+    as files with "extra bytes" VLR dimensions carry.  For tests and for exporting synthetic scenes."""
     xyz = np.asarray(xyz, dtype=np.float64)
     n = xyz.shape[0]
-    fmt = 2 if rgb is not None else 0
-    record_len = _MIN_RECORD[fmt]
+    fmt = point_format if point_format is not None else (2 if rgb is not None else 0)
+    if fmt not in _MIN_RECORD:
+        raise ValueError("point format %r" % (fmt,))
+    if rgb is not None and fmt not in _RGB_OFFSET:
+        raise ValueError("point format %d has no colour" % fmt)
+    if fmt >= 6:
+        version = (1, 4)
+    record_len = _MIN_RECORD[fmt] + int(extra_bytes)
     offset = xyz.min(axis=0) if n else np.zeros(3)
     ints = np.round((xyz - offset) / scale).astype("<i4")
     rec = np.zeros((n, record_len), dtype=np.uint8)
     rec[:, :12] = ints.view(np.uint8).reshape(n, 12)
-    rec[:, 15] = np.asarray(classification, dtype=np.uint8) & 0x1F
+    cls = np.asarray(classification, dtype=np.uint8)
+    rec[:, _CLASS_OFFSET[fmt]] = cls & 0x1F if fmt < 6 else cls
     if rgb is not None:
-        rec[:, 20:26] = np.ascontiguousarray(np.asarray(rgb, dtype="<u2")).view(np.uint8).reshape(n, 6)
-    header_size = 227
+        o = _RGB_OFFSET[fmt]
+        rec[:, o:o + 6] = np.ascontiguousarray(np.asarray(rgb, dtype="<u2")).view(np.uint8).reshape(n, 6)
+    if extra_bytes:
+        rec[:, _MIN_RECORD[fmt]:] = (np.arange(n)[:, None] + np.arange(extra_bytes)[None, :]) & 0xFF
+    header_size = 375 if version >= (1, 4) else 227
     head = bytearray(header_size)
     head[0:4] = b"LASF"
     head[24], head[25] = version
     struct.pack_into("<HI", head, 94, header_size, header_size)
     head[104] = fmt
-    struct.pack_into("<HI", head, 105, record_len, n)
+    struct.pack_into("<HI", head, 105, record_len, n if (fmt < 6 and n < 2 ** 32) else 0)     # legacy count: 0 for formats >= 6
     struct.pack_into("<6d", head, 131, scale, scale, scale, offset[0], offset[1], offset[2])
     mx, mn = (xyz.max(axis=0), xyz.min(axis=0)) if n else (np.zeros(3), np.zeros(3))
     struct.pack_into("<6d", head, 179, mx[0], mn[0], mx[1], mn[1], mx[2], mn[2])
+    if header_size >= 375:
+        struct.pack_into("<Q", head, 247, n)
     with open(path, "wb") as fh:
         fh.write(bytes(head))
         fh.write(rec.tobytes())
