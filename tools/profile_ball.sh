@@ -18,4 +18,7 @@ run ball_cube "--kernel-trace --stats" python3 "$root/tools/run_ball.py" cube 50
 run ball_facade "--kernel-trace --stats" python3 "$root/tools/run_ball.py" facade 50
 run pmc_fetch "--pmc FETCH_SIZE --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
 run pmc_write "--pmc WRITE_SIZE --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
+run pmc_sq1 "--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
+run pmc_sq2 "--pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_BUSY_CYCLES --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
+run control "--kernel-trace --stats" python3 "$root/bench.py" --model pointnet_sem_seg --steps 5 --warmup 3
 ls -la "$out"
