@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--kind", default="cube", choices=("cube", "facade"))
     ap.add_argument("--model", default="pointnet2_sem_seg", choices=("pointnet2_sem_seg", "pointnet_sem_seg"),
                     help="pointnet_sem_seg = the plain-PointNet control of BASELINE configs[4] (pointwise MLPs only, one GPU)")
+    ap.add_argument("--rgb-off", action="store_true",
+                    help="BASELINE configs[3]: the geometry-only 4096x6 blocks of the reference's --RGB_OFF (steps only; the roofline leg keeps the north_star shape D = 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -202,11 +204,12 @@ def main():
         return
 
     # synthetic blocks of this rank (weak scaling: 16 blocks per GPU), resident in HBM
-    blocks, labels, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind,
+    step_channels = 6 if args.rgb_off else CHANNELS
+    blocks, labels, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, step_channels, args.kind,
                                            NUM_CLASSES)
     x = torch.from_numpy(np.ascontiguousarray(blocks.transpose(0, 2, 1))).to(dev)     # [B,C,N]
     y = torch.from_numpy(labels).to(dev)
-    model = M.get_model(NUM_CLASSES, CHANNELS - 6)
+    model = M.get_model(NUM_CLASSES, step_channels - 6)
     filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     model = model.to(dev)
@@ -243,7 +246,8 @@ def main():
     # captured graph, between HIP events on the launch stream.  What building the plan costs is reported beside it
     # (the producer launches: binning + row packing; and what the binning launch adds to an FPS call), and so is the
     # self-contained entry pn2_ball_query_group, which needs no workspace and keeps its own kernel.
-    pts = x.permute(0, 2, 1).contiguous()
+    rblocks, _, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind, NUM_CLASSES)
+    pts = torch.from_numpy(rblocks).to(dev)
     xyz = pts[:, :, :3].contiguous()
     start = torch.zeros(PER_GPU_BATCH, dtype=torch.long, device=dev)
     _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, 1024, 0.1, CHANNELS, start)
@@ -363,8 +367,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "pointnet2_sem_seg fwd+bwd+Adam, batch=16x4096x9 synthetic %s blocks per GPU, "
-                                   "npoint=[1024,256,64,16] nsample=32, 18 classes (BASELINE configs[1])" % args.kind,
+            "config": {"workload": "pointnet2_sem_seg fwd+bwd+Adam, batch=16x4096x%d synthetic %s blocks per GPU, "
+                                   "npoint=[1024,256,64,16] nsample=32, 18 classes (BASELINE %s)"
+                                   % (step_channels, args.kind, "configs[3], --RGB_OFF" if args.rgb_off else "configs[1]"),
                        "global_batch": world * PER_GPU_BATCH, "points_per_block": BLOCK_POINTS,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm",
