@@ -27,12 +27,49 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v3i __attribute__((ext_vector_type(3)));
 
+// rows [b][j] = [x, y, z, feats(D), 0...] at pitch rp: one float4 of one row per call
+__device__ __forceinline__ void pack_row_quarter(long long t, const float *__restrict__ xyz, const float *__restrict__ points, int N, int D,
+                                                 int rp, char *__restrict__ tables, size_t table_stride, size_t rows_off)
+{
+    const int qpr = rp >> 4;                       // float4 per packed row
+    const long long row = t / qpr;
+    const int part = (int)(t - row * qpr);
+    const int b = (int)(row / N), j = (int)(row - (long long)b * N);
+    const float *x = xyz + (size_t)row * 3;
+    const float *f = points ? points + (size_t)row * D : nullptr;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = part * 4 + c;              // column of the grouped row: 0..2 xyz, 3.. feats
+        v[c] = col < 3 ? x[col] : (col < 3 + D ? f[col - 3] : 0.0f);
+    }
+    *reinterpret_cast<float4 *>(tables + (size_t)b * table_stride + rows_off + (size_t)j * rp + (size_t)part * 16) =
+        make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256) void ball_pack_rows_kernel(const float *__restrict__ xyz, const float *__restrict__ points, int N, int D,
+                                                             int rp, char *__restrict__ tables, size_t table_stride, size_t rows_off,
+                                                             long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < total) pack_row_quarter(t, xyz, points, N, D, rp, tables, table_stride, rows_off);
+}
+
 // ---- stand-alone producers of the plan: one workgroup per block bins and plans, many pack the rows ---------------
 template <int P>
 __global__ __launch_bounds__(1024) void ball_bin_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N, int S, int D,
-                                                        float r2, char *__restrict__ tables, size_t table_stride)
+                                                        float r2, char *__restrict__ tables, size_t table_stride, int B,
+                                                        const float *__restrict__ points, long long pack_total)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= B) {
+        // workgroups past the B binning ones pack the gather rows in the same launch (they run on the CUs the
+        // one-workgroup-per-block binning leaves idle)
+        const long long t = ((long long)blockIdx.x - B) * 1024 + threadIdx.x;
+        if (t < pack_total)
+            pack_row_quarter(t, xyz, points, N, D, pn2::bin_row_pitch(D), tables, table_stride, pn2::bin_rows_off(N, S));
+        return;
+    }
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *bx = xyz + (size_t)b * N * 3;
     PN2_STAMP(0);
@@ -57,29 +94,6 @@ __global__ __launch_bounds__(1024) void ball_bin_kernel(const float *__restrict_
     }
     PN2_STAMP(1);
     pn2::bin_block<1024, P>(px, py, pz, N, r2, D, new_xyz + (size_t)b * S * 3, S, smem, tables + (size_t)b * table_stride);
-}
-
-// rows [b][j] = [x, y, z, feats(D), 0...] at pitch rp: thread = one float4 of one row
-__global__ __launch_bounds__(256) void ball_pack_rows_kernel(const float *__restrict__ xyz, const float *__restrict__ points, int N, int D,
-                                                             int rp, char *__restrict__ tables, size_t table_stride, size_t rows_off,
-                                                             long long total)
-{
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int qpr = rp >> 4;                       // float4 per packed row
-    const long long row = t / qpr;
-    const int part = (int)(t - row * qpr);
-    const int b = (int)(row / N), j = (int)(row - (long long)b * N);
-    const float *x = xyz + (size_t)row * 3;
-    const float *f = points ? points + (size_t)row * D : nullptr;
-    float v[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int col = part * 4 + c;              // column of the grouped row: 0..2 xyz, 3.. feats
-        v[c] = col < 3 ? x[col] : (col < 3 + D ? f[col - 3] : 0.0f);
-    }
-    *reinterpret_cast<float4 *>(tables + (size_t)b * table_stride + rows_off + (size_t)j * rp + (size_t)part * 16) =
-        make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ---- the query ---------------------------------------------------------------------------------------------------
@@ -337,14 +351,20 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_binned_kernel(
 
 namespace pn2 {
 // the binning / planning kernel alone (also the second launch of pn2_farthest_point_sample_plan)
-int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S, int D, float r2, char *plans, hipStream_t stream)
+int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S, int D, float r2, char *plans, hipStream_t stream,
+                    const float *pack_points = nullptr, bool pack = false)
 {
     const size_t lds = bin_lds_bytes<1024>();
     const size_t stride = bin_block_bytes(N, S, D);
-    if (N <= 1024) hipLaunchKernelGGL(ball_bin_kernel<1>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
-    else if (N <= 2048) hipLaunchKernelGGL(ball_bin_kernel<2>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
-    else if (N <= 4096) hipLaunchKernelGGL(ball_bin_kernel<4>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
-    else hipLaunchKernelGGL(ball_bin_kernel<8>, dim3(B), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride);
+    const long long pack_total = pack ? (long long)B * N * (bin_row_pitch(D) >> 4) : 0;
+    const long long grid = (long long)B + (pack_total + 1023) / 1024;
+    if (grid > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
+#define PN2_BIN(P) hipLaunchKernelGGL(ball_bin_kernel<P>, dim3((unsigned)grid), dim3(1024), lds, stream, xyz, new_xyz, N, S, D, r2, plans, stride, B, pack_points, pack_total)
+    if (N <= 1024) PN2_BIN(1);
+    else if (N <= 2048) PN2_BIN(2);
+    else if (N <= 4096) PN2_BIN(4);
+    else PN2_BIN(8);
+#undef PN2_BIN
     return PN2_LAUNCH_RC();
 }
 }  // namespace pn2
@@ -386,9 +406,8 @@ PN2_EXPORT int pn2_ball_plan(double radius, const float *xyz, const float *new_x
     if ((reinterpret_cast<uintptr_t>(plans) & 127) != 0) return PN2_ERR_SHAPE;
     if (B == 0) return PN2_OK;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
-    const int rc = pn2::launch_ball_bin(xyz, new_xyz, B, N, S, D, r2, static_cast<char *>(plans), static_cast<hipStream_t>(stream_));
-    if (rc != PN2_OK) return rc;
-    return pn2_ball_pack_rows(xyz, points, B, N, S, D, plans, stream_);
+    // binning workgroups and row-packing workgroups in ONE launch
+    return pn2::launch_ball_bin(xyz, new_xyz, B, N, S, D, r2, static_cast<char *>(plans), static_cast<hipStream_t>(stream_), points, true);
 }
 
 PN2_EXPORT int pn2_ball_query_group_planned(double radius, int nsample, const void *plans, const float *xyz, const float *new_xyz,

@@ -5,7 +5,8 @@
 #include "pn2_common.h"
 
 namespace pn2 {
-int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S, int D, float r2, char *plans, hipStream_t stream);
+int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S, int D, float r2, char *plans, hipStream_t stream,
+                    const float *pack_points = nullptr, bool pack = false);
 }
 
 namespace {

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Gradient distance of the HIP train step from the oracle network in fp32 and fp64 (same fp32 geometry):
-    python tools/gradcheck.py [B] [kind]      (GPU box)"""
+    python tests/gradcheck_tool.py [B] [kind]      (GPU box)"""
 import os
 import sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ may use the oracle; tools/ may not
 sys.path.insert(0, REPO)
 import numpy as np
 import torch

@@ -543,7 +543,7 @@ def _bias_under_batchnorm(k):
 def _assert_gradient_close(got, ref, key, l2=2e-2, mx=6e-2):
     """Gradient bar.  ReLU / max-pool gates sit on pre-activations that are exactly representable noise away from 0,
     so two correct evaluation orders flip a few gates differently; every flip moves some gradient entries by a
-    finite amount.  Measured on this network (tools/gradcheck.py, B = 2 and 16, cube and facade, worst tensor): the
+    finite amount.  Measured on this network (tests/gradcheck_tool.py, B = 2 and 16, cube and facade, worst tensor): the
     oracle's torch-CPU fp32 evaluation -- the reference's arithmetic -- sits 0.67-1.35 % (relative L2) and
     1.4-2.3 % (max-norm) from an fp64 evaluation of the same step; the HIP step 0.65-1.3 % and 1.9-4.6 %.  No
     fp32 evaluation meets 1 % max-norm against fp64; the bar is 2 % in relative L2 (the flips average out) and 6 %
