@@ -189,6 +189,7 @@ __device__ __forceinline__ void ball_query_tile(unsigned logical, unsigned *bm, 
                 test(q0, true);
                 test(q1, true);
             }
+            // (four masked loads per round trip here: facade 14.4 -> 13.8 us, but the sparse case 9.35 -> 9.6 us)
         }
     } else {
         for (int j = lg; j < N; j += LPC) {
