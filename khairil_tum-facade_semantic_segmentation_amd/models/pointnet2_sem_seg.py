@@ -84,8 +84,7 @@ class get_model(nn.Module):
         if prepared is not None:
             pts, xyz3 = prepared
         else:
-            pts = xyz.permute(0, 2, 1).contiguous()      # [B,N,C]
-            xyz3 = pts[:, :, :3].contiguous()
+            pts, xyz3 = ops.input_blocks(xyz, True, None)   # [B,N,C] rows and [B,N,3] coordinates in one pass
         geo = [xyz3]
         feat = [pts]
         for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):

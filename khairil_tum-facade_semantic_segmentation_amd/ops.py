@@ -7,8 +7,11 @@ import torch
 
 from . import _lib
 
+import os
+
 _ERR = {}
 _ERROR_MODE = "lazy"
+_SKIP_INPLACE = os.environ.get("PN2_SKIP_INPLACE", "0") == "1"
 
 
 def set_error_mode(mode):
@@ -306,7 +309,7 @@ def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None):
     """grad_points[B,N,D] = scatter-add of grad_out[B,...,Cg][..., col0:col0+D] at idx; with
     inv = invert_index(idx, N) the same sum as an atomic-free gather in a fixed order.
     into = a contiguous fp32 [B,N,D] tensor that already holds another gradient of the same points: the scatter then
-    accumulates onto it in place (no zero fill, no add afterwards) and returns it."""
+    accumulates onto a copy of it (no zero fill, no add afterwards) and returns that."""
     dev = _dev(grad_out, idx)
     lib = _lib.load()
     grad_out, idx = _f32c(grad_out), _i64c(idx)
@@ -317,7 +320,10 @@ def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None):
         out = _gather_sum(grad_out, M, col0, inv, None, 1, N, D)
         return out if into is None else out + into
     if into is not None and into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == (B, N, D):
-        gp = into
+        # accumulate on top of the other gradient: a COPY of it (autograd owns `into` -- it may be the same tensor
+        # another node receives -- so it is never modified in place; PN2_SKIP_INPLACE=1 restores the in-place form,
+        # valid for the network's own wiring where the skip gradient has a single consumer: 15 us per step)
+        gp = into if _SKIP_INPLACE else into.clone()
     else:
         gp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
         if into is not None:
