@@ -137,6 +137,55 @@ __global__ __launch_bounds__(256) void group_points_vec4_kernel(const float *__r
     reinterpret_cast<float4 *>(grouped + (size_t)bs * K * ldg)[f] = v;
 }
 
+// The same quads numbered flat over one batch's [S, K, ldg/4] block (blockIdx.y = batch): no partly filled last
+// workgroup per centroid (K*ldg/4 = 544 at SA2 left every third workgroup 7/8 idle), the gathers issued before any
+// branch on their result, and 16-byte write-through stores (the block is read next by another kernel, possibly on
+// another XCD, and never again by this one).
+typedef int gp_v4i __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void group_points_flat_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                const float *__restrict__ points, const int64_t *__restrict__ idx,
+                                                                int N, int S, int K, int D, int ldg, unsigned q_magic,
+                                                                unsigned k_magic, unsigned batch_quads,
+                                                                float *__restrict__ grouped, int32_t *err_count)
+{
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= batch_quads) return;
+    const unsigned b = blockIdx.y;
+    const int qpr = ldg >> 2;
+    const unsigned row = qpr == 1 ? t : __umulhi(t, q_magic);      // s*K + k
+    const int q = (int)(t - row * (unsigned)qpr);
+    const unsigned s = K == 1 ? row : __umulhi(row, k_magic);
+    const int64_t j = idx[(size_t)b * S * K + row];
+    const bool ok = j >= 0 && j < N;
+    const unsigned jj = ok ? (unsigned)j : 0u;
+    const float *prow = points + ((size_t)b * N + jj) * D;         // only dereferenced when D > 0
+    const int c0 = q == 0 ? 0 : 4 * q - 3;                         // first feature this quad reads
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (c0 + 4 <= D) {                                             // a full quad of features (quad 0 keeps only the first)
+        const f32x4u t4 = *reinterpret_cast<const f32x4u *>(prow + c0);
+        v = make_float4(t4.x, t4.y, t4.z, t4.w);
+    } else {
+        if (c0 < D) v.x = prow[c0];
+        if (c0 + 1 < D) v.y = prow[c0 + 1];
+        if (c0 + 2 < D) v.z = prow[c0 + 2];
+    }
+    if (q == 0) {
+        const f32x3u p3 = *reinterpret_cast<const f32x3u *>(xyz + ((size_t)b * N + jj) * 3);
+        const f32x3u c3 = *reinterpret_cast<const f32x3u *>(new_xyz + ((size_t)b * S + s) * 3);
+        v = make_float4(p3.x - c3.x, p3.y - c3.y, p3.z - c3.z, v.x);                          // :128, :131
+    }
+    if (!ok) {
+        v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q == 0 && err_count) atomicAdd(err_count, 1);
+    }
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(grouped + (size_t)b * batch_quads * 4, 0,
+                                                                         (int)(batch_quads * 16u), 0x00020000);
+    gp_v4i w;
+    w.x = __float_as_int(v.x); w.y = __float_as_int(v.y); w.z = __float_as_int(v.z); w.w = __float_as_int(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(w, grs, (int)(t * 16u), 0, 16);   // aux 16 = sc1: write-through
+}
+
 __global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src,
                                                               const float *__restrict__ dst, long long total,
                                                               int N, int M, float *__restrict__ out)
@@ -266,6 +315,17 @@ PN2_EXPORT int pn2_group_points(const float *xyz, const float *new_xyz, const fl
         const int qpr = ldg >> 2;
         const long long quads = (long long)K * qpr;
         const long long nyq = (quads + 255) / 256;
+        const long long batch_quads = (long long)S * quads;
+        // flat numbering: magic divisions are exact below 2^32 / divisor, the store offset is 32-bit
+        if (B <= 65535 && batch_quads * 16 < (1LL << 31) && batch_quads < (1LL << 32) / (qpr > K ? qpr : K) &&
+            pn2::tune_get("group_flat", 1)) {
+            const unsigned qm = qpr > 1 ? (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u : 0u;
+            const unsigned km = K > 1 ? (unsigned)((1ULL << 32) / (unsigned)K) + 1u : 0u;
+            hipLaunchKernelGGL(group_points_flat_kernel, dim3((unsigned)((batch_quads + 255) / 256), (unsigned)B), dim3(256), 0,
+                               static_cast<hipStream_t>(stream_), xyz, new_xyz, points, idx, N, S, K, D, ldg, qm, km,
+                               (unsigned)batch_quads, grouped, err_count);
+            return PN2_LAUNCH_RC();
+        }
         if (nyq <= 65535) {
             const unsigned qmagic = qpr > 1 ? (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u : 0u;
             hipLaunchKernelGGL(group_points_vec4_kernel, dim3((unsigned)rows, (unsigned)nyq), dim3(256), 0,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer micro-benchmark of the individual HIP kernels (GPU box only):
-    python tools/kbench.py [ball|fps|nn|all]
+    python tools/kbench.py [ball|fps|nn|group|all]
 Times back-to-back launches with events on the launch stream; prints us/launch and GB/s."""
 import os
 import sys
@@ -90,6 +90,21 @@ def bench_nn():
         print("three_nn N=%d S=%d: %.1f us | interpolate D=%d: %.1f us | backward %.1f us" % (N, S, t, D, t2, t3))
 
 
+def bench_group():
+    """The separate grouping pass the model's main stream runs at every level (indices come from the geometry
+    stream), at the padded pitches the MLP reads."""
+    rs = np.random.RandomState(0)
+    for (N, S, r, D) in ((4096, 1024, 0.1, 9), (1024, 256, 0.2, 64), (256, 64, 0.4, 128), (64, 16, 0.8, 256)):
+        xyz = torch.from_numpy(synth.make_xyz(rs, 16, N, "cube")).cuda()
+        pts = torch.randn(16, N, D, device="cuda")
+        _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, S)
+        idx, _ = ops._ball_query_group_raw(r, 32, xyz, new_xyz, None, False)
+        ldg = (3 + D + 3) // 4 * 4
+        t = timeit(lambda: ops.group_points(xyz, new_xyz, pts, idx, pad_to=4))
+        out_bytes = 16 * S * 32 * ldg * 4
+        print("group N=%d S=%d D=%d pitch %d: %.1f us (%.1f MB written, %.0f GB/s)" % (N, S, D, ldg, t, out_bytes / 1e6, out_bytes / t / 1e3))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("ball", "all"):
@@ -98,3 +113,5 @@ if __name__ == "__main__":
         bench_fps()
     if what in ("nn", "all"):
         bench_nn()
+    if what in ("group", "all"):
+        bench_group()
