@@ -172,6 +172,30 @@ int pn2_bn_finalize(const float *partial, int P, int C, double count, const floa
                     float *scale, float *shift, float *mean_out, float *invstd_out, long long *num_batches_tracked,
                     pn2_stream_t stream);
 
+/* The forward GEMM of a stack's LAST layer when its rows are max-pooled in groups of 32 (nsample = 32,
+ * models/pointnet2_utils.py:200): prologue 0 / 1 of pn2_mlp_gemm, W [N][K], and in the epilogue -- one 32-row
+ * accumulator block is one group -- the largest and the smallest z of every (group, column) with the first row that
+ * holds it: pool_max / pool_min [M/32][N] floats, pool_amax / pool_amin [M/32][N] bytes.  The pooled activation is
+ * then relu(scale*(scale >= 0 ? zmax : zmin) + shift) (rounding is monotone), chosen by pn2_bn_finalize_out once the
+ * batch statistics exist; z is written as usual (the backward reads it) but never re-read by the forward.
+ * M % 32 == 0.  PN2_ERR_UNSUPPORTED (nothing launched) when the operands do not allow the pipelined kernels. */
+int pn2_mlp_gemm_pool32(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
+                        const float *scale, const float *shift, const float *w, int ldw, const float *bias, float *out,
+                        int ldo, int M, int N, float *stat_partial, float *pool_max, float *pool_min,
+                        unsigned char *pool_amax, unsigned char *pool_amin, pn2_stream_t stream);
+
+/* pn2_bn_finalize and the stack's output in ONE launch (models/pointnet2_utils.py:198-200 / :314):
+ *   pool_max == NULL: y[rows_out][C] = max(scale*z + shift, 0), z with row pitch ldz;
+ *   pool_max != NULL: y / argk [rows_out][C] selected from the extrema of pn2_mlp_gemm_pool32 (argk = 0 where y == 0
+ *                     or scale == 0: all 32 rows tie and torch.max reports the first).
+ * partial == NULL: scale / shift are inputs (eval mode), nothing is finalized.  C % 4 == 0. */
+int pn2_bn_finalize_out(const float *partial, int P, int C, double count, const float *gamma, const float *beta,
+                        float eps, float momentum, const float *momentum_dev, float *running_mean, float *running_var,
+                        float *scale, float *shift, float *mean_out, float *invstd_out, long long *num_batches_tracked,
+                        const float *z, int ldz, const float *pool_max, const float *pool_min,
+                        const unsigned char *pool_amax, const unsigned char *pool_amin, long long rows_out, float *y,
+                        unsigned char *argk, pn2_stream_t stream);
+
 /* eval-mode coefficients from the running estimates */
 int pn2_bn_eval_coeff(int C, const float *gamma, const float *beta, const float *running_mean,
                       const float *running_var, float eps, float *scale, float *shift, pn2_stream_t stream);

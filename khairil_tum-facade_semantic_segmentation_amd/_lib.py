@@ -32,6 +32,10 @@ SIGNATURES = {
     "pn2_mlp_gemm": [_vp, _ci, _ci, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _ci, _vp,
                      _vp, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_bn_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_mlp_gemm_pool32": [_vp, _ci, _ci, _vp, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _vp, _vp, _vp,
+                            _vp, _vp, _vp],
+    "pn2_bn_finalize_out": [_vp, _ci, _ci, _cd, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
+                            _vp, _vp, _vp, _cl, _vp, _vp, _vp],
     "pn2_bn_eval_coeff": [_ci, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp],
     "pn2_bn_relu_out": [_vp, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_mlp_dw_partials": [_ci, _ci, _ci],
@@ -94,6 +98,9 @@ def load():
         fn.restype = ctypes.c_char_p if name == "pn2_error_string" else (ctypes.c_longlong if name == "pn2_ball_plan_bytes" else _ci)
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -3      # PN2_ERR_UNSUPPORTED (include/pn2_hip.h): the entry does not cover these operands, nothing was launched
 
 
 def check(rc, what):

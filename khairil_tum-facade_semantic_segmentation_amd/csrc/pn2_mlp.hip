@@ -54,6 +54,13 @@ struct GemmArgs {
     // sum(out) and sum(out * (zprev-mmean)*minvstd) go to stat_partial instead
     const float *mask_z, *mscale, *mshift, *mmean, *minvstd;
     int ldm;
+    // pooled forward epilogue (pool_max != null; rows come in groups of 32 = one 32-row accumulator block): per
+    // group and column the largest and the smallest z with the first row that holds it.  max over the group of
+    // relu(scale*z+shift) is relu(scale*zmax+shift) for scale >= 0 and relu(scale*zmin+shift) otherwise (rounding is
+    // monotone), so the max-pool (models/pointnet2_utils.py:200) needs no second pass over z once the batch
+    // statistics are known (bn_finalize_out_kernel).
+    float *pool_max, *pool_min;
+    unsigned char *pool_amax, *pool_amin;
 };
 
 // Epilogue of one 32x32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half): bias,
@@ -62,10 +69,12 @@ struct GemmArgs {
 // < M (FULL) stores in straight-line code: vmcnt counts stores too on gfx9, and with a load result first used
 // inside per-row branches the compiler puts s_waitcnt vmcnt(0) in front of every store, i.e. one store
 // acknowledgement round trip per row (16 per block).
-template <bool FULL, bool BWD>
+template <bool FULL, bool BWD, bool POOL = false>
 __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16 &acc, int row0, int half, int col,
                                                  float &csum, float &csq)
 {
+    float vmax = -INFINITY, vmin = INFINITY;
+    int imax = 0, imin = 0;
     float bv = 0.f;
     if (p.bias) bv = p.bias[col];
     const bool second = p.out2 && col >= p.nsplit;
@@ -100,10 +109,25 @@ __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16
                 csq += z * z;
             }
             ob[(size_t)row * ld] = z;
+            if (POOL) {                                              // rows ascend with r: '>' keeps the first
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (z > vmax) { vmax = z; imax = rr; }
+                if (z < vmin) { vmin = z; imin = rr; }
+            }
         }
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);          // keep the next block's loads (16 more registers) behind these stores
+    if (POOL) {
+        // the other 16 rows of this column live in lane ^ 32
+        const float omax = __shfl_xor(vmax, 32), omin = __shfl_xor(vmin, 32);
+        const int oimax = __shfl_xor(imax, 32), oimin = __shfl_xor(imin, 32);
+        if (omax > vmax || (omax == vmax && oimax < imax)) { vmax = omax; imax = oimax; }
+        if (omin < vmin || (omin == vmin && oimin < imin)) { vmin = omin; imin = oimin; }
+        const size_t o = (size_t)(row0 >> 5) * p.N + col;
+        if (half == 0) { p.pool_max[o] = vmax; p.pool_amax[o] = (unsigned char)imax; }
+        else { p.pool_min[o] = vmin; p.pool_amin[o] = (unsigned char)imin; }
+    }
 }
 
 template <bool BWD_POSSIBLE>
@@ -115,7 +139,8 @@ __device__ __forceinline__ void gemm_store_block_any(const GemmArgs &p, const f3
         if (full) gemm_store_block<true, true>(p, acc, row0, half, col, csum, csq);
         else gemm_store_block<false, true>(p, acc, row0, half, col, csum, csq);
     } else {
-        if (full) gemm_store_block<true, false>(p, acc, row0, half, col, csum, csq);
+        if (full && p.pool_max) gemm_store_block<true, false, true>(p, acc, row0, half, col, csum, csq);
+        else if (full) gemm_store_block<true, false>(p, acc, row0, half, col, csum, csq);
         else gemm_store_block<false, false>(p, acc, row0, half, col, csum, csq);
     }
 }
@@ -821,60 +846,147 @@ __device__ __forceinline__ void strided_sum_pair_any(const float *__restrict__ a
     else { strided_sum_any(a, stride, py, P, a0, a1); strided_sum_any(b, stride, py, P, b0, b1); }
 }
 
-// partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
-// :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
-// estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
-// double in a fixed order (deterministic).
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partial, int P, int C, double count,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, float momentum, const float *__restrict__ momentum_dev,
-                                                          float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var, float *__restrict__ scale,
-                                                          float *__restrict__ shift, float *__restrict__ mean_out,
-                                                          float *__restrict__ invstd_out, long long *num_batches_tracked)
+struct BnFinArgs {
+    const float *partial;           // [P][2][C]; null: scale / shift are given (eval mode), nothing to finalize
+    int P, C;
+    double count;
+    const float *gamma, *beta;
+    float eps, momentum;
+    const float *momentum_dev;
+    float *running_mean, *running_var, *scale, *shift, *mean_out, *invstd_out;
+    long long *num_batches_tracked;
+};
+
+// The 32 channels of column block `cb` by one 1024-thread workgroup (32 channels x 32 partial slices).  Every caller
+// gets the same scale / shift bit for bit (in sScale / sShift after the barrier the CALLER places); only a `writer`
+// stores them and updates the running estimates.
+__device__ __forceinline__ void bn_finalize_block(const BnFinArgs &a, int cb, bool writer, float *sScale, float *sShift)
 {
+    const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = cb * 32 + cl;
+    const int C = a.C, P = a.P;
+    if (!a.partial) {
+        if (py == 0) { sScale[cl] = c < C ? a.scale[c] : 0.f; sShift[cl] = c < C ? a.shift[c] : 0.f; }
+        return;
+    }
     // momentum: a device word when given (so that a captured launch follows the per-epoch schedule of the reference
     // loop, localfunctions.py:191-195), else the host value; negative = nn.BatchNorm(momentum=None): the cumulative
     // average 1 / num_batches_tracked, the counter then being incremented by the CALLER beforehand (all workgroups
     // read it here)
-    if (momentum_dev) momentum = *momentum_dev;
+    float momentum = a.momentum;
+    if (a.momentum_dev) momentum = *a.momentum_dev;
     const bool cumulative = momentum < 0.0f;
-    if (cumulative) momentum = (num_batches_tracked && *num_batches_tracked > 0) ? 1.0f / (float)*num_batches_tracked : 0.0f;
-    if (!cumulative && num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    if (cumulative) momentum = (a.num_batches_tracked && *a.num_batches_tracked > 0) ? 1.0f / (float)*a.num_batches_tracked : 0.0f;
+    if (!cumulative && a.num_batches_tracked && writer && cb == 0 && threadIdx.x == 0) *a.num_batches_tracked += 1;
     __shared__ double sS[32][33], sQ[32][33];
-    const int cl = threadIdx.x & 31, py = threadIdx.x >> 5;      // 32 channels x 32 partial slices
-    const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     // the layer parameters travel with the partials (one memory round trip for the whole kernel, which runs 22
     // times per step), not after the reduction
     const int cc = min(c, C - 1);
-    const float g = gamma ? gamma[cc] : 1.0f, b = beta ? beta[cc] : 0.0f;
-    const float rm = running_mean ? running_mean[cc] : 0.f, rv = running_var ? running_var[cc] : 0.f;
+    const float g = a.gamma ? a.gamma[cc] : 1.0f, b = a.beta ? a.beta[cc] : 0.0f;
+    const float rm = (writer && a.running_mean) ? a.running_mean[cc] : 0.f, rv = (writer && a.running_var) ? a.running_var[cc] : 0.f;
     if (c < C) {
         // a thread's partials are all loaded before the first add: the loads are independent, a load-add loop
         // would pay one memory round trip per iteration
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;            // <= 8 terms each: fp32 is exact enough here
-        strided_sum_pair_any(partial + c, partial + C + c, (size_t)2 * C, py, P, s0, s1, q0, q1);
+        strided_sum_pair_any(a.partial + c, a.partial + C + c, (size_t)2 * C, py, P, s0, s1, q0, q1);
         s = (double)s0 + (double)s1;
         q = (double)q0 + (double)q1;
     }
     sS[py][cl] = s;
     sQ[py][cl] = q;
     __syncthreads();
-    if (py != 0 || c >= C) return;
-    for (int i = 1; i < 32; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    scale[c] = g * invstd;
-    shift[c] = b - (float)mean * g * invstd;
-    if (mean_out) mean_out[c] = (float)mean;
-    if (invstd_out) invstd_out[c] = invstd;
-    if (running_mean) running_mean[c] = (1.0f - momentum) * rm + momentum * (float)mean;
-    if (running_var) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
+    if (py == 0) {
+        for (int i = 1; i < 32; ++i) { s += sS[i][cl]; q += sQ[i][cl]; }
+        const double mean = s / a.count;
+        double var = q / a.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sc = g * invstd, sh = b - (float)mean * g * invstd;
+        sScale[cl] = sc;
+        sShift[cl] = sh;
+        if (writer && c < C) {
+            a.scale[c] = sc;
+            a.shift[c] = sh;
+            if (a.mean_out) a.mean_out[c] = (float)mean;
+            if (a.invstd_out) a.invstd_out[c] = invstd;
+            if (a.running_mean) a.running_mean[c] = (1.0f - momentum) * rm + momentum * (float)mean;
+            if (a.running_var) {
+                const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+                a.running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
+            }
+        }
+    }
+}
+
+// partial[P][2][C] -> BatchNorm coefficients of a train-mode layer (models/pointnet2_utils.py:198 /
+// :314 with nn.BatchNorm semantics: biased variance for normalisation, unbiased for the running
+// estimate, running = (1-m)*running + m*batch).  One thread per channel, partials summed in
+// double in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinArgs a)
+{
+    __shared__ float sScale[32], sShift[32];
+    bn_finalize_block(a, blockIdx.x, true, sScale, sShift);
+}
+
+// The same followed, in the same launch, by the output of the stack: workgroup (cb, slice) finalizes column block cb
+// (redundantly over the slices: a few hundred KB of L2 hits; slice 0 is the writer) and then emits its slice of the
+// rows for those 32 channels --
+//   apply  (pool_max == null): y[r][c] = max(scale*z[r][c] + shift, 0)
+//   select (pool_max != null): from the per-group extrema the GEMM epilogue left (GemmArgs::pool_max ...):
+//          y = max(scale*(scale >= 0 ? zmax : zmin) + shift, 0), argk = the row that held it (0 when y == 0 or
+//          scale == 0: every row of the group ties and torch.max returns the first).
+// One launch instead of bn_finalize + bn_relu_out, and the pooled form never re-reads z.
+struct BnOutArgs {
+    const float *z;
+    int ldz;
+    const float *pool_max, *pool_min;
+    const unsigned char *pool_amax, *pool_amin;
+    long long rows_out;
+    float *y;                       // [rows_out][C]
+    unsigned char *argk;            // [rows_out][C], select only
+};
+
+__global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOutArgs o)
+{
+    __shared__ float sScale[32], sShift[32];
+    bn_finalize_block(a, blockIdx.x, blockIdx.y == 0, sScale, sShift);
+    __syncthreads();
+    const int cq = (threadIdx.x & 7) * 4, c = blockIdx.x * 32 + cq;
+    if (c >= a.C) return;                                       // C % 4 == 0
+    const float4 sc = make_float4(sScale[cq], sScale[cq + 1], sScale[cq + 2], sScale[cq + 3]);
+    const float4 sh = make_float4(sShift[cq], sShift[cq + 1], sShift[cq + 2], sShift[cq + 3]);
+    const long long per = (o.rows_out + gridDim.y - 1) / gridDim.y;
+    const long long r1 = min(o.rows_out, per * (blockIdx.y + 1));
+    const int C = a.C;
+    if (!o.pool_max) {
+#pragma unroll 4
+        for (long long r = per * blockIdx.y + (threadIdx.x >> 3); r < r1; r += 128) {
+            const float4 v = *reinterpret_cast<const float4 *>(o.z + (size_t)r * o.ldz + c);
+            float4 y;
+            y.x = fmaxf(sc.x * v.x + sh.x, 0.f);
+            y.y = fmaxf(sc.y * v.y + sh.y, 0.f);
+            y.z = fmaxf(sc.z * v.z + sh.z, 0.f);
+            y.w = fmaxf(sc.w * v.w + sh.w, 0.f);
+            *reinterpret_cast<float4 *>(o.y + (size_t)r * C + c) = y;
+        }
+    } else {
+#pragma unroll 2
+        for (long long r = per * blockIdx.y + (threadIdx.x >> 3); r < r1; r += 128) {
+            const size_t e = (size_t)r * C + c;
+            const float4 hi = *reinterpret_cast<const float4 *>(o.pool_max + e);
+            const float4 lo = *reinterpret_cast<const float4 *>(o.pool_min + e);
+            const uchar4 ah = *reinterpret_cast<const uchar4 *>(o.pool_amax + e);
+            const uchar4 al = *reinterpret_cast<const uchar4 *>(o.pool_amin + e);
+            float4 y;
+            uchar4 k;
+#define PN2_SEL(f) do { const bool up = sc.f >= 0.f; y.f = fmaxf(sc.f * (up ? hi.f : lo.f) + sh.f, 0.f); \
+                        k.f = (y.f > 0.f && sc.f != 0.f) ? (up ? ah.f : al.f) : (unsigned char)0; } while (0)
+            PN2_SEL(x); PN2_SEL(y); PN2_SEL(z); PN2_SEL(w);
+#undef PN2_SEL
+            *reinterpret_cast<float4 *>(o.y + e) = y;
+            *reinterpret_cast<uchar4 *>(o.argk + e) = k;
+        }
     }
 }
 
@@ -1528,13 +1640,14 @@ PN2_EXPORT int pn2_mlp_gemm_max_partials(int M)
     return ntiles < 512 ? (ntiles < 1 ? 1 : ntiles) : 512;
 }
 
-PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
-                            const float *scale, const float *shift, const float *mean, const float *invstd,
-                            const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w, int ldw,
-                            int w_is_kn,
-                            const float *bias, float *out, int ldo, float *out2, int ldo2, int nsplit, int M, int N,
-                            float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
-                            const float *mmean, const float *minvstd, pn2_stream_t stream_)
+static int mlp_gemm_impl(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
+                         const float *scale, const float *shift, const float *mean, const float *invstd,
+                         const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w, int ldw,
+                         int w_is_kn,
+                         const float *bias, float *out, int ldo, float *out2, int ldo2, int nsplit, int M, int N,
+                         float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
+                         const float *mmean, const float *minvstd, float *pool_max, float *pool_min,
+                         unsigned char *pool_amax, unsigned char *pool_amin, pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(x1);
     PN2_REQUIRE_PTR(w);
@@ -1561,6 +1674,7 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
     a.K = prologue == PRO_BN_BWD ? K1 : K1 + K2;
     a.stat_partial = stat_partial;
     a.mask_z = mask_z; a.mscale = mscale; a.mshift = mshift; a.mmean = mmean; a.minvstd = minvstd; a.ldm = ldm;
+    a.pool_max = pool_max; a.pool_min = pool_min; a.pool_amax = pool_amax; a.pool_amin = pool_amin;
     // float4 staging needs 16-B aligned rows and a concat boundary on a multiple of 4
     bool vec4 = (ld1 % 4 == 0) && aligned16(x1) && (K1 % 4 == 0) && (a.K % 4 == 0);
     if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
@@ -1613,9 +1727,39 @@ PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, i
     // the pipelined kernel also stages the weight tile with float4 loads
     bool pipe = vec4 && (ldw % 4 == 0) && aligned16(w) && (w_is_kn ? (N % 4 == 0) : true) && pn2::tune_get("mlp_pipe", 1);
     if (prologue == PRO_BN_BWD && argk) pipe = pipe && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
+    if (pool_max && !pipe) return PN2_ERR_UNSUPPORTED;          // only the pipelined epilogues pool
     if (N <= 32) return launch_gemm<32>(a, prologue, vec4, pipe, gx, stream);
     if (N <= 64) return launch_gemm<64>(a, prologue, vec4, pipe, gx, stream);
     return launch_gemm<128>(a, prologue, vec4, pipe, gx, stream);
+}
+
+PN2_EXPORT int pn2_mlp_gemm(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
+                            const float *scale, const float *shift, const float *mean, const float *invstd,
+                            const float *c1, const float *c2, const unsigned char *argk, int pool_k, const float *w, int ldw,
+                            int w_is_kn,
+                            const float *bias, float *out, int ldo, float *out2, int ldo2, int nsplit, int M, int N,
+                            float *stat_partial, const float *mask_z, int ldm, const float *mscale, const float *mshift,
+                            const float *mmean, const float *minvstd, pn2_stream_t stream_)
+{
+    return mlp_gemm_impl(x1, ld1, K1, x2, ld2, K2, prologue, scale, shift, mean, invstd, c1, c2, argk, pool_k, w, ldw, w_is_kn,
+                         bias, out, ldo, out2, ldo2, nsplit, M, N, stat_partial, mask_z, ldm, mscale, mshift, mmean, minvstd,
+                         nullptr, nullptr, nullptr, nullptr, stream_);
+}
+
+PN2_EXPORT int pn2_mlp_gemm_pool32(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
+                                   const float *scale, const float *shift, const float *w, int ldw, const float *bias,
+                                   float *out, int ldo, int M, int N, float *stat_partial, float *pool_max, float *pool_min,
+                                   unsigned char *pool_amax, unsigned char *pool_amin, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(pool_max);
+    PN2_REQUIRE_PTR(pool_min);
+    PN2_REQUIRE_PTR(pool_amax);
+    PN2_REQUIRE_PTR(pool_amin);
+    if (prologue != PRO_NONE && prologue != PRO_BN_RELU) return PN2_ERR_SHAPE;
+    if (M % 32 != 0) return PN2_ERR_SHAPE;                      // groups of 32 rows = whole accumulator blocks
+    return mlp_gemm_impl(x1, ld1, K1, x2, ld2, K2, prologue, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w,
+                         ldw, 0, bias, out, ldo, nullptr, 0, 0, M, N, stat_partial, nullptr, 0, nullptr, nullptr, nullptr,
+                         nullptr, pool_max, pool_min, pool_amax, pool_amin, stream_);
 }
 
 PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count, const float *gamma,
@@ -1627,9 +1771,53 @@ PN2_EXPORT int pn2_bn_finalize(const float *partial, int P, int C, double count,
     PN2_REQUIRE_PTR(scale);
     PN2_REQUIRE_PTR(shift);
     if (P <= 0 || C <= 0 || count <= 0) return PN2_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_), partial,
-                       P, C, count, gamma, beta, eps, momentum, momentum_dev, running_mean, running_var, scale, shift, mean_out,
-                       invstd_out, num_batches_tracked);
+    BnFinArgs a;
+    a.partial = partial; a.P = P; a.C = C; a.count = count; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.momentum = momentum; a.momentum_dev = momentum_dev; a.running_mean = running_mean; a.running_var = running_var;
+    a.scale = scale; a.shift = shift; a.mean_out = mean_out; a.invstd_out = invstd_out;
+    a.num_batches_tracked = num_batches_tracked;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_), a);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_bn_finalize_out(const float *partial, int P, int C, double count, const float *gamma,
+                                   const float *beta, float eps, float momentum, const float *momentum_dev,
+                                   float *running_mean, float *running_var, float *scale, float *shift, float *mean_out,
+                                   float *invstd_out, long long *num_batches_tracked, const float *z, int ldz,
+                                   const float *pool_max, const float *pool_min, const unsigned char *pool_amax,
+                                   const unsigned char *pool_amin, long long rows_out, float *y, unsigned char *argk,
+                                   pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(scale);
+    PN2_REQUIRE_PTR(shift);
+    PN2_REQUIRE_PTR(y);
+    if (C <= 0 || rows_out < 0 || (partial && (P <= 0 || count <= 0))) return PN2_ERR_SHAPE;
+    if (pool_max) {
+        if (!pool_min || !pool_amax || !pool_amin || !argk) return PN2_ERR_NULL;
+        if (!aligned16(pool_max) || !aligned16(pool_min) || (reinterpret_cast<uintptr_t>(pool_amax) & 3) ||
+            (reinterpret_cast<uintptr_t>(pool_amin) & 3) || (reinterpret_cast<uintptr_t>(argk) & 3))
+            return PN2_ERR_UNSUPPORTED;
+    } else {
+        PN2_REQUIRE_PTR(z);
+        if (ldz < C) return PN2_ERR_SHAPE;
+        if (ldz % 4 != 0 || !aligned16(z)) return PN2_ERR_UNSUPPORTED;
+    }
+    if (C % 4 != 0 || !aligned16(y)) return PN2_ERR_UNSUPPORTED;
+    BnFinArgs a;
+    a.partial = partial; a.P = P; a.C = C; a.count = count; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.momentum = momentum; a.momentum_dev = momentum_dev; a.running_mean = running_mean; a.running_var = running_var;
+    a.scale = scale; a.shift = shift; a.mean_out = mean_out; a.invstd_out = invstd_out;
+    a.num_batches_tracked = num_batches_tracked;
+    BnOutArgs o;
+    o.z = z; o.ldz = ldz; o.pool_max = pool_max; o.pool_min = pool_min; o.pool_amax = pool_amax; o.pool_amin = pool_amin;
+    o.rows_out = rows_out; o.y = y; o.argk = argk;
+    // row slices: 128 rows per pass of a workgroup; at most 64 slices (every slice repeats the finalize)
+    long long slices = (rows_out + 127) / 128;
+    const long long cap = pn2::tune_get("bn_out_slices", 64);
+    if (slices > cap) slices = cap;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(bn_finalize_out_kernel, dim3((C + 31) / 32, (unsigned)slices), dim3(1024), 0,
+                       static_cast<hipStream_t>(stream_), a, o);
     return PN2_LAUNCH_RC();
 }
 

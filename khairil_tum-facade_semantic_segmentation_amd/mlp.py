@@ -25,6 +25,10 @@ _DW_SIDE_MAX_ROWS = int(os.environ.get("PN2_DW_SIDE_MAX_ROWS", "0"))
 # the layer below) in one pass over the activations (pn2_mlp_bwd_layer); PN2_FUSED_BWD=0 keeps the
 # two-kernel path (pn2_mlp_gemm prologue 2 + pn2_mlp_dw) for A/B runs.
 _FUSED_BWD = os.environ.get("PN2_FUSED_BWD", "1") == "1"
+# The last layer's BatchNorm finalize and the stack's output (BatchNorm + ReLU, max over nsample = 32 from the extrema
+# the GEMM epilogue recorded) run in one launch (pn2_bn_finalize_out); PN2_FUSED_OUT=0 keeps pn2_bn_finalize +
+# pn2_bn_relu_out (which re-reads z) for A/B runs.
+_FUSED_OUT = os.environ.get("PN2_FUSED_OUT", "1") == "1"
 _side_streams = {}
 
 
@@ -104,6 +108,7 @@ class _MLPStack(torch.autograd.Function):
         training = bns[0].training
         f32 = dict(dtype=torch.float32, device=dev)
         zs, coefs = [], []
+        y = argk = None
         with torch.cuda.device(dev):
             for l in range(L):
                 w, b, gamma, beta = params[4 * l:4 * l + 4]
@@ -112,33 +117,69 @@ class _MLPStack(torch.autograd.Function):
                 z = torch.empty((M, Co), **f32)
                 P = lib.pn2_mlp_gemm_max_partials(M)
                 stat = torch.empty((P, 2, Co), **f32) if training else None
+                last = l == L - 1
+                fuse_out = last and _FUSED_OUT and pool_k in (0, 32) and Co % 4 == 0
+                pooled = None
                 if l == 0:
-                    _gemm(lib, dev, x1, K1, x2, K2, PRO_NONE, None, None, 0, w2, w2.stride(0), 0, b, z, M, Co, stat)
+                    src = (x1, K1, x2, K2, PRO_NONE, None, None)
                 else:
                     zp = zs[-1]
-                    sc, sh = coefs[-1][0], coefs[-1][1]
-                    _gemm(lib, dev, zp, zp.shape[1], None, 0, PRO_BN_RELU, (sc, sh, None, None, None, None), None, 0,
-                          w2, w2.stride(0), 0, b, z, M, Co, stat)
+                    src = (zp, zp.shape[1], None, 0, PRO_BN_RELU, coefs[-1][0], coefs[-1][1])
+                if fuse_out and pool_k == 32 and M % 32 == 0:
+                    # the max over nsample falls out of the epilogue: per (group, channel) the extrema of z
+                    pooled = (torch.empty((M // 32, Co), **f32), torch.empty((M // 32, Co), **f32),
+                              torch.empty((M // 32, Co), dtype=torch.uint8, device=dev),
+                              torch.empty((M // 32, Co), dtype=torch.uint8, device=dev))
+                    a1, ak1, a2, ak2, pro, psc, psh = src
+                    rc = lib.pn2_mlp_gemm_pool32(_ptr(a1), a1.stride(0), ak1, _ptr(a2), 0 if a2 is None else a2.stride(0), ak2,
+                                                 pro, _ptr(psc), _ptr(psh), _ptr(w2), w2.stride(0), _ptr(b), _ptr(z),
+                                                 z.stride(0), M, Co, _ptr(stat), _ptr(pooled[0]), _ptr(pooled[1]),
+                                                 _ptr(pooled[2]), _ptr(pooled[3]), _stream(dev))
+                    if rc == _lib.ERR_UNSUPPORTED:      # operands the pipelined kernels do not take: nothing was launched
+                        pooled = None
+                    else:
+                        _lib.check(rc, "pn2_mlp_gemm_pool32")
+                if pooled is None:
+                    a1, ak1, a2, ak2, pro, psc, psh = src
+                    _gemm(lib, dev, a1, ak1, a2, ak2, pro, None if pro == PRO_NONE else (psc, psh, None, None, None, None),
+                          None, 0, w2, w2.stride(0), 0, b, z, M, Co, stat)
+                    fuse_out = fuse_out and pool_k == 0
                 scale, shift = torch.empty(Co, **f32), torch.empty(Co, **f32)
                 bn = bns[l]
+                out_args = None
+                if fuse_out:
+                    rows_out = M // 32 if pooled is not None else M
+                    y = torch.empty((rows_out, Co), **f32)
+                    argk = torch.empty((rows_out, Co), dtype=torch.uint8, device=dev) if pooled is not None else None
+                    pm = pooled or (None, None, None, None)
+                    out_args = (_ptr(z), z.stride(0), _ptr(pm[0]), _ptr(pm[1]), _ptr(pm[2]), _ptr(pm[3]), rows_out, _ptr(y),
+                                _ptr(argk), _stream(dev))
                 if training:
                     mean, invstd = torch.empty(Co, **f32), torch.empty(Co, **f32)
                     mom, mom_dev = momentum_word(bn, dev)
                     track = bn.track_running_stats and bn.running_mean is not None
                     if mom < 0.0 and track and bn.num_batches_tracked is not None:
                         bn.num_batches_tracked.add_(1)        # momentum=None: the kernel reads the bumped counter
-                    rc = lib.pn2_bn_finalize(_ptr(stat), P, Co, float(M), _ptr(gamma), _ptr(beta), float(bn.eps), mom,
-                                             _ptr(mom_dev), _ptr(bn.running_mean) if track else None,
-                                             _ptr(bn.running_var) if track else None, _ptr(scale), _ptr(shift),
-                                             _ptr(mean), _ptr(invstd),
-                                             _ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else None,
-                                             _stream(dev))
-                    _lib.check(rc, "pn2_bn_finalize")
+                    fin_args = (_ptr(stat), P, Co, float(M), _ptr(gamma), _ptr(beta), float(bn.eps), mom,
+                                _ptr(mom_dev), _ptr(bn.running_mean) if track else None,
+                                _ptr(bn.running_var) if track else None, _ptr(scale), _ptr(shift),
+                                _ptr(mean), _ptr(invstd),
+                                _ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else None)
+                    if out_args is not None:
+                        rc = lib.pn2_bn_finalize_out(*fin_args, *out_args)
+                        _lib.check(rc, "pn2_bn_finalize_out")
+                    else:
+                        rc = lib.pn2_bn_finalize(*fin_args, _stream(dev))
+                        _lib.check(rc, "pn2_bn_finalize")
                     coefs.append((scale, shift, mean, invstd))
                 else:
                     rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                                                float(bn.eps), _ptr(scale), _ptr(shift), _stream(dev))
                     _lib.check(rc, "pn2_bn_eval_coeff")
+                    if out_args is not None:
+                        rc = lib.pn2_bn_finalize_out(None, 0, Co, 1.0, None, None, float(bn.eps), 0.0, None, None, None,
+                                                     _ptr(scale), _ptr(shift), None, None, None, *out_args)
+                        _lib.check(rc, "pn2_bn_finalize_out")
                     # mean / invstd of the frozen statistics: only needed if someone back-propagates
                     # through an eval-mode stack (BatchNorm is then a fixed affine map)
                     coefs.append((scale, shift, bn.running_mean.detach().clone(),
@@ -146,7 +187,9 @@ class _MLPStack(torch.autograd.Function):
                 zs.append(z)
             Co = zs[-1].shape[1]
             argk2, k2 = None, 0
-            if pool_k > 255:
+            if y is not None:
+                pass                                    # emitted by pn2_bn_finalize_out
+            elif pool_k > 255:
                 # the winning row of a group is recorded in 8 bits: pool in two stages, k1 <= 255 rows per sub-group
                 # (with the BatchNorm + ReLU), then the k2 = pool_k / k1 sub-group maxima of each group (already
                 # activated: identity coefficients) -- group_all pools a whole cloud (pointnet2_utils.py:141-158, :200)

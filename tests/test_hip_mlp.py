@@ -162,3 +162,50 @@ def test_stack_eval_backward(env, M, K1, K2, widths, pool_k):
         close(c.bias.grad, rc.bias.grad, "db%d" % l)           # a real gradient here: BN no longer removes the mean
         close(b.weight.grad, rb.weight.grad, "dgamma%d" % l)
         close(b.bias.grad, rb.bias.grad, "dbeta%d" % l)
+
+
+@pytest.mark.parametrize("M,K1,widths,pool_k", [
+    (4096, 12, (32, 32, 64), 32),                # SA1: N = 64 pipelined tiles
+    (8192, 68, (64, 64, 128), 32),               # SA2: 8-wave form
+    (1024, 260, (256, 256, 512), 32),            # SA4: 32-row tiles, four column blocks
+    (640, 128, (128, 128, 128), 0),              # FP1: apply form
+    (1000, 64, (256, 128), 0),                   # ragged row slices
+    (66016, 16, (32, 64), 32),                   # many groups per slice, 64 slices
+])
+@pytest.mark.parametrize("mode", ("train", "eval"))
+def test_fused_output_matches_two_launch_form(env, M, K1, widths, pool_k, mode):
+    """pn2_bn_finalize_out (+ the pooled epilogue of pn2_mlp_gemm_pool32) against pn2_bn_finalize + pn2_bn_relu_out on
+    the same stack: the same bits in y, the running estimates and every gradient -- with negative and zero BatchNorm
+    weights in the last layer (max over the group then comes from the SMALLEST z, or from no z at all)."""
+    import copy
+    torch, mlp = env
+    convs, bns = make_stack(torch, K1, widths, seed=M + 3)
+    with torch.no_grad():
+        bns[-1].weight[::3] *= -1.0
+        bns[-1].weight[5] = 0.0
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K1, generator=g).cuda()
+    if pool_k:
+        x[1] = x[0]                              # a tie inside a group
+    results = []
+    assert mlp._FUSED_OUT
+    try:
+        for fused in (True, False):
+            mlp._FUSED_OUT = fused
+            c, b = copy.deepcopy(convs).cuda(), copy.deepcopy(bns).cuda()
+            (c.train(), b.train()) if mode == "train" else (c.eval(), b.eval())
+            xi = x.clone().requires_grad_(True)
+            y = mlp.mlp_stack(xi, None, c, b, pool_k)
+            go = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).cuda()
+            y.backward(go)
+            results.append((y.detach(), xi.grad, [p.grad for p in list(c.parameters()) + list(b.parameters())],
+                            [t.clone() for bn in b for t in (bn.running_mean, bn.running_var)]))
+    finally:
+        mlp._FUSED_OUT = True
+    (y1, gx1, gp1, rs1), (y0, gx0, gp0, rs0) = results
+    assert torch.equal(y1, y0)
+    assert torch.equal(gx1, gx0)
+    for a, b_ in zip(gp1, gp0):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(rs1, rs0):
+        assert torch.equal(a, b_)
