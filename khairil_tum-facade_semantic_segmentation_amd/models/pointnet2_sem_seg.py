@@ -92,7 +92,11 @@ class get_model(nn.Module):
             if i > 0 and pre is not None and _SKIP_IN_SCATTER:
                 # feat[i] feeds this level's grouping AND a feature-propagation skip: route the skip through the grouping
                 # op's second output, so that both gradients meet inside its scatter (no zero fill, no add kernel)
-                g, f, feat[-1] = sa.forward_cl(geo[-1], feat[-1], geometry=pre, skip=True)
+                # The skip's only consumer is a feature-propagation stack whose backward (mlp._MLPStack) returns a tensor
+                # it has just allocated, so the scatter may add onto that tensor itself (no copy: 3 x 11 us per step);
+                # with the torch-op A/B path nothing is known about who else holds the gradient.
+                g, f, feat[-1] = sa.forward_cl(geo[-1], feat[-1], geometry=pre,
+                                               skip=True if _utils._TORCH_MLP else "inplace")
             else:
                 g, f = sa.forward_cl(geo[-1], feat[-1], geometry=pre)
             geo.append(g)

@@ -161,7 +161,8 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
         """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C'].
         `geometry` = a precomputed (new_xyz, idx[, inverse index]) tuple from geometry().
         skip (with `geometry`): a third result, `points` again for the caller's skip connection (ops.group_points
-        with_skip: the two gradients of the points are then summed inside the grouping backward)."""
+        with_skip: the two gradients of the points are then summed inside the grouping backward; skip="inplace": onto
+        the skip gradient itself, which the caller states has no other reader)."""
         alias = points
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz, points)
@@ -169,7 +170,7 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
             new_xyz, idx = geometry[0], geometry[1]
             inv = geometry[2] if len(geometry) > 2 else None       # ops.invert_index(idx, N): atomic-free backward
             if skip and points is not None:
-                grouped, alias = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv, with_skip=True)
+                grouped, alias = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv, with_skip=skip)
             else:
                 grouped = ops.group_points(xyz, new_xyz, points, idx, pad_to=4, inv=inv)
         else:

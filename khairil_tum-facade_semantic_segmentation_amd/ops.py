@@ -305,11 +305,12 @@ def _gather_sum(src, rows_src, col0, inv, weight, ediv, nkeys, D):
     return out
 
 
-def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None):
+def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None, into_owned=False):
     """grad_points[B,N,D] = scatter-add of grad_out[B,...,Cg][..., col0:col0+D] at idx; with
     inv = invert_index(idx, N) the same sum as an atomic-free gather in a fixed order.
     into = a contiguous fp32 [B,N,D] tensor that already holds another gradient of the same points: the scatter then
-    accumulates onto a copy of it (no zero fill, no add afterwards) and returns that."""
+    accumulates onto a copy of it (no zero fill, no add afterwards) and returns that; into_owned = the caller vouches
+    that nobody else reads `into` (see group_points(with_skip="inplace")): no copy either."""
     dev = _dev(grad_out, idx)
     lib = _lib.load()
     grad_out, idx = _f32c(grad_out), _i64c(idx)
@@ -323,7 +324,7 @@ def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None):
         # accumulate on top of the other gradient: a COPY of it (autograd owns `into` -- it may be the same tensor
         # another node receives -- so it is never modified in place; PN2_SKIP_INPLACE=1 restores the in-place form,
         # valid for the network's own wiring where the skip gradient has a single consumer: 15 us per step)
-        gp = into if _SKIP_INPLACE else into.clone()
+        gp = into if (_SKIP_INPLACE or into_owned) else into.clone()
     else:
         gp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
         if into is not None:
@@ -383,6 +384,7 @@ class _GroupPoints(torch.autograd.Function):
         ctx.save_for_backward(idx, *((inv_off, inv_ent) if ctx.has_inv else ()))
         ctx.shape = (N, D)
         ctx.with_skip = bool(with_skip)
+        ctx.skip_owned = with_skip == "inplace"
         if with_skip:
             # second output: the points themselves, for the caller's OTHER use of them (the skip connection into
             # feature propagation) -- its gradient then arrives here and the scatter accumulates onto it
@@ -398,19 +400,24 @@ class _GroupPoints(torch.autograd.Function):
             return None, None, None, None, None, None, None, None
         if gout is None:
             return None, None, gskip, None, None, None, None, None
-        return None, None, index_points_backward(gout, idx, N, D, col0=3, inv=inv, into=gskip), None, None, None, None, None
+        return (None, None, index_points_backward(gout, idx, N, D, col0=3, inv=inv, into=gskip, into_owned=ctx.skip_owned),
+                None, None, None, None, None)
 
 
 def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None, with_skip=False):
     """[xyz[idx]-new_xyz, points[idx]] for a given idx (models/pointnet2_utils.py:127-132).
     inv = invert_index(idx, N): the backward then gathers instead of scatter-adding.
     with_skip: also returns `points` again (same storage); a caller that uses the points a second time (skip connection)
-    through THAT tensor gets both gradients summed inside the scatter instead of by a zero fill + add."""
+    through THAT tensor gets both gradients summed inside the scatter instead of by a zero fill + add.  The scatter
+    accumulates onto a COPY of the skip gradient; with_skip="inplace" is the caller's statement that the gradient arriving
+    for the second output has no other reader (a fresh tensor from the consumer's backward, as in the network's own wiring:
+    mlp._MLPStack.backward hands over a tensor it just allocated) -- the scatter then adds onto it directly."""
     dev = _dev(xyz, new_xyz, points, idx)
     if points is not None:
         points = points.to(torch.float32).contiguous()
     io, ie = inv if inv is not None else (None, None)
-    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to, io, ie, bool(with_skip and points is not None))
+    out = _GroupPoints.apply(_f32c(xyz), _f32c(new_xyz), points, _i64c(idx), pad_to, io, ie,
+                             (with_skip if with_skip == "inplace" else bool(with_skip)) if points is not None else False)
     _after_fault_op(dev, "group_points")
     if with_skip and points is None:
         return out, None
