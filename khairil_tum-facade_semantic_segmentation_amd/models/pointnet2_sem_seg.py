@@ -47,17 +47,25 @@ class get_model(nn.Module):
         when `angles` [B] is given.  Pass the result as `prepared=` to compute_geometry() / forward()."""
         return ops.input_blocks(xyz, True, angles)
 
-    def compute_geometry(self, xyz=None, prepared=None):
+    def compute_geometry(self, xyz=None, prepared=None, group_first=False):
         """Everything in the forward pass that depends on the input coordinates only: the FPS /
         ball-query pyramid of the four SA levels and the 3-NN tables of the four FP levels
         (SURVEY.md 3.3).  Returns a flat list of tensors that forward(geometry=...) consumes; it
         can be computed ahead of time (another stream, one batch early) because no learned
-        quantity feeds it."""
+        quantity feeds it.
+        group_first (with `prepared`): the first level's grouped rows [B,S,K,12] too -- its features are the network input,
+        so the launch that finds the indices gathers the rows as well (the fused query + group kernel of DESIGN 4.2)
+        and forward(geometry=...) starts at the first GEMM; slot [32] of the list (None when the shape is outside the
+        planned path)."""
         cur = prepared[1] if prepared is not None else xyz.permute(0, 2, 1)[:, :, :3].contiguous()
         levels = [cur]
         out, inv = [], []
+        grouped1 = None
         for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
-            new_xyz, idx = sa.geometry(levels[-1])
+            if i == 0 and group_first and prepared is not None:
+                new_xyz, idx, grouped1 = sa.geometry(levels[-1], points=prepared[0])
+            else:
+                new_xyz, idx = sa.geometry(levels[-1])
             out += [new_xyz, idx]
             # A transposed index for the grouping backward is possible too (ops.group_points(inv=...)), but the
             # per-point lists have a heavy tail (a point sits in up to ~100 balls) and the gather-sum is then
@@ -70,7 +78,8 @@ class get_model(nn.Module):
             out += [idx3, w3]
             pair = ops.invert_index(idx3, levels[lvl + 1].shape[1])
             inv += list(pair) if pair is not None else [None, None]
-        return out + inv                                 # [0:8] SA, [8:16] FP, [16:24] SA inverses, [24:32] FP inverses
+        # [0:8] SA, [8:16] FP, [16:24] SA inverses, [24:32] FP inverses, [32] grouped rows of level 1
+        return out + inv + ([grouped1] if group_first else [])
 
     @staticmethod
     def _inverse(geometry, slot):
@@ -89,7 +98,9 @@ class get_model(nn.Module):
         feat = [pts]
         for i, sa in enumerate((self.sa1, self.sa2, self.sa3, self.sa4)):
             pre = None if geometry is None else (geometry[2 * i], geometry[2 * i + 1]) + self._inverse(geometry, i)
-            if i > 0 and pre is not None and _SKIP_IN_SCATTER:
+            if i == 0 and pre is not None and len(geometry) > 32 and geometry[32] is not None and not pts.requires_grad:
+                g, f = sa.forward_cl(geo[-1], feat[-1], geometry=pre, grouped=geometry[32])
+            elif i > 0 and pre is not None and _SKIP_IN_SCATTER:
                 # feat[i] feeds this level's grouping AND a feature-propagation skip: route the skip through the grouping
                 # op's second output, so that both gradients meet inside its scatter (no zero fill, no add kernel)
                 # The skip's only consumer is a feature-propagation stack whose backward (mlp._MLPStack) returns a tensor

@@ -145,27 +145,40 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
             self.mlp_convs.append(nn.Conv2d(ci, co, 1))
             self.mlp_bns.append(nn.BatchNorm2d(co))
 
-    def geometry(self, xyz, start=None):
+    def geometry(self, xyz, start=None, points=None):
         """The part of the level that depends on xyz only: FPS centroids and
-        ball-query indices.  xyz [B,N,3] -> (new_xyz [B,S,3], idx [B,S,K])."""
+        ball-query indices.  xyz [B,N,3] -> (new_xyz [B,S,3], idx [B,S,K]).
+        points [B,N,D] (features that need no gradient -- the network input): a third result, the grouped rows
+        [B,S,K,pad4(3+D)] from the SAME launch that finds the indices (the planned query gathers them from the plan's
+        packed rows); None when the shape is outside the planned path."""
         if start is None:
             start = _next_start(xyz.device)
         B, N, _ = xyz.shape
         if xyz.is_cuda and ops.plan_supported(B, N, self.npoint) and self.nsample <= 64:
+            if points is not None:
+                _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, self.npoint, self.radius, points.shape[2], start)
+                idx, grouped = ops.ball_query_group(self.radius, self.nsample, xyz, new_xyz, points, pad_to=4, plan=plan)
+                return new_xyz, idx, grouped
             _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, self.npoint, self.radius, 0, start)
-            return new_xyz, ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz, plan=plan)
+            idx = ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz, plan=plan)
+            return (new_xyz, idx) if points is None else (new_xyz, idx, None)
         _, new_xyz = ops.farthest_point_sample_with_xyz(xyz, self.npoint, start)
-        return new_xyz, ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+        idx = ops.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+        return (new_xyz, idx) if points is None else (new_xyz, idx, None)
 
-    def forward_cl(self, xyz, points, start=None, geometry=None, skip=False):
+    def forward_cl(self, xyz, points, start=None, geometry=None, skip=False, grouped=None):
         """Channel-last form: xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], feats [B,S,C'].
         `geometry` = a precomputed (new_xyz, idx[, inverse index]) tuple from geometry().
         skip (with `geometry`): a third result, `points` again for the caller's skip connection (ops.group_points
         with_skip: the two gradients of the points are then summed inside the grouping backward; skip="inplace": onto
-        the skip gradient itself, which the caller states has no other reader)."""
+        the skip gradient itself, which the caller states has no other reader).
+        grouped (with `geometry`): the level's grouped rows, already built by geometry(points=...) -- no grouping pass
+        here (points that need a gradient must not take this route: the rows are a constant to autograd)."""
         alias = points
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz, points)
+        elif geometry is not None and grouped is not None:
+            new_xyz = geometry[0]
         elif geometry is not None:
             new_xyz, idx = geometry[0], geometry[1]
             inv = geometry[2] if len(geometry) > 2 else None       # ops.invert_index(idx, N): atomic-free backward

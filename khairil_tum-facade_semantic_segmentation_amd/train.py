@@ -149,6 +149,7 @@ class SemSegTrainer:
             ncls = model.conv2.out_channels if hasattr(model, "conv2") else int(metrics)
             self.metrics = SegMetrics(ncls, next(model.parameters()).device)
         self._side = torch.cuda.Stream() if self.prefetch else None
+        self._prepares = hasattr(model, "prepare_input")        # the pyramid hands the prepared input rows over too
         self._geo_next = None            # pyramid computed for the coming step
         self._geo_next_src = None        # identity (data_ptr, version, shape) of the batch it was computed from
         self._captured_mode = None       # (exchange, world) the graphs were captured for
@@ -227,10 +228,12 @@ class SemSegTrainer:
         """The pyramid of a batch; with augmentation the rotated input it was computed on travels with it (last two
         entries: rows [B,N,C], coordinates [B,N,3]) so that the forward one step later runs on the same rotation."""
         with torch.no_grad():
-            if not self.augment:
+            if not self._prepares:
                 return self.model.compute_geometry(blocks_cf)
-            prepared = self.model.prepare_input(blocks_cf, self._draw_angles(blocks_cf))
-            return self.model.compute_geometry(prepared=prepared) + [prepared[0], prepared[1]]
+            # the input rows are laid out (and rotated) on this branch too, and the first level's grouped rows come from
+            # the launch that finds its indices: the critical branch starts at the first GEMM
+            prepared = self.model.prepare_input(blocks_cf, self._draw_angles(blocks_cf) if self.augment else None)
+            return self.model.compute_geometry(prepared=prepared, group_first=True) + [prepared[0], prepared[1]]
 
     def _launch_prefetch(self, next_blocks_cf):
         """Enqueue the geometry pyramid of `next_blocks_cf` on the side stream."""
@@ -252,11 +255,11 @@ class SemSegTrainer:
 
     def _forward_backward(self, blocks_cf, target, geometry=None):
         self.grads.zero()
-        if self.augment:
-            if geometry is not None:
-                prepared, geometry = (geometry[-2], geometry[-1]), geometry[:-2]
-            else:
-                prepared = self.model.prepare_input(blocks_cf, self._draw_angles(blocks_cf))
+        if geometry is not None and self._prepares:
+            prepared, geometry = (geometry[-2], geometry[-1]), geometry[:-2]
+            pred, _ = self.model(blocks_cf, geometry=geometry, prepared=prepared)
+        elif self.augment:
+            prepared = self.model.prepare_input(blocks_cf, self._draw_angles(blocks_cf))
             pred, _ = self.model(blocks_cf, geometry=geometry, prepared=prepared)
         else:
             pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
