@@ -315,6 +315,14 @@ int pn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   float *state, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
                   pn2_stream_t stream);
 
+/* The same update reading every parameter tensor's gradient where backward left it: grads[i] (HOST array of n_tensors
+ * device pointers; NULL = zero gradient) belongs to elements offsets[i] .. offsets[i+1] of `param` (HOST array of
+ * n_tensors + 1 ascending element offsets, offsets[0] = 0).  No packing pass; the pointers travel in the kernel
+ * arguments, so a captured launch keeps them.  n_tensors <= 192, fewer than 2^32 elements, else PN2_ERR_UNSUPPORTED. */
+int pn2_adam_step_scattered(float *param, int n_tensors, const float *const *grads, const long long *offsets,
+                            float *exp_avg, float *exp_avg_sq, const float *lr, float *state, double beta1, double beta2,
+                            double eps, double weight_decay, double grad_scale, pn2_stream_t stream);
+
 /* ---- whole-scene inference aggregation --------------------------------------
  * add_vote(vote_label_pool, point_idx, pred_label, weight)            localfunctions.py:339-346
  * vote_pool[P][C] int32 += 1 at (point_idx[m], label[m]) for every m < M whose weight is neither 0

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pn2_nll_loss": [_vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp, _vp, _vp, _vp],
     "pn2_nll_loss_backward": [_vp, _vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp],
     "pn2_adam_step": [_vp, _vp, _vp, _vp, _cl, _vp, _vp, _cd, _cd, _cd, _cd, _cd, _vp],
+    "pn2_adam_step_scattered": [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _cd, _cd, _vp],
     "pn2_sample_blocks": [_vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _ci, _ci, _ci, _ci, _cd, ctypes.POINTER(ctypes.c_double), _ci, _ci,
                           ctypes.c_ulonglong, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_input_blocks": [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],

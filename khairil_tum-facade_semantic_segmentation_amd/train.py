@@ -95,11 +95,37 @@ class FlatAdam:
         self.state = torch.zeros(3, dtype=torch.float32, device=dev)      # step, 1-beta1^t, sqrt(1-beta2^t)
         self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self._offsets = None
 
     def set_lr(self, lr):
         """New learning rate (the reference re-sets param_group['lr'] every epoch, localfunctions.py:187-190);
         a device scalar, so captured graphs pick it up."""
         self.lr.fill_(float(lr))
+
+    def step_scattered(self, grads, grad_scale=1.0):
+        """The update with the gradients where backward left them (one tensor or None per parameter, in the order of
+        `params`): no packing pass.  False when the library does not take this many tensors (pack and use step())."""
+        import ctypes
+        lib = self._lib.load()
+        dev = self.flat.device
+        n = len(self.params)
+        if self._offsets is None:
+            off = [0]
+            for p in self.params:
+                off.append(off[-1] + p.numel())
+            self._offsets = (ctypes.c_longlong * (n + 1))(*off)
+        held = [None if g is None else (g if (g.is_contiguous() and g.dtype == torch.float32) else g.float().contiguous())
+                for g in grads]
+        ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in held])
+        with torch.cuda.device(dev):
+            rc = lib.pn2_adam_step_scattered(self.flat.data_ptr(), n, ptrs, self._offsets, self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), self.lr.data_ptr(), self.state.data_ptr(),
+                                             self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
+                                             torch.cuda.current_stream(dev).cuda_stream)
+        if rc == self._lib.ERR_UNSUPPORTED:
+            return False
+        self._lib.check(rc, "pn2_adam_step_scattered")
+        return True
 
     def step(self, flat_grad, grad_scale=1.0):
         lib = self._lib.load()
@@ -271,9 +297,11 @@ class SemSegTrainer:
 
     def _optimizer_step(self, grad_scale=1.0):
         if self.flat_adam is not None:
-            if self.grads.buffer is None:
+            # no exchange packed the gradients: the update reads them where backward left them
+            if self.grads.buffer is None and not self.flat_adam.step_scattered([p.grad for p in self.grads.params], grad_scale):
                 self.grads.pack()
-            self.flat_adam.step(self.grads.buffer, grad_scale)
+            if self.grads.buffer is not None:
+                self.flat_adam.step(self.grads.buffer, grad_scale)
             self.grads.buffer = None
         else:
             self.optimizer.step()
@@ -346,9 +374,11 @@ class SemSegTrainer:
                 self._side.wait_stream(torch.cuda.current_stream())       # backward no longer reads `cur`
                 with torch.cuda.stream(self._side):
                     self._geo_flat.copy_(new_flat)
-            flat = self.grads.pack()                    # .grad become views of one flat buffer
-            if not exchange:
-                self.flat_adam.step(flat)
+            flat = None
+            if exchange or not self.flat_adam.step_scattered([p.grad for p in self.grads.params]):
+                flat = self.grads.pack()                # .grad become views of one flat buffer
+                if not exchange:
+                    self.flat_adam.step(flat)
             if self.prefetch:
                 torch.cuda.current_stream().wait_stream(self._side)       # join
         if exchange:

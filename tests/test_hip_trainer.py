@@ -150,6 +150,30 @@ def test_flat_adam_matches_torch_adam():
     assert float(ours.state[0]) == 3.0
 
 
+def test_adam_reads_gradients_where_backward_left_them():
+    """pn2_adam_step_scattered (one gradient pointer per parameter tensor, a missing gradient = zeros; tensor sizes
+    that are no multiples of 4, so float4 groups straddle tensors) gives the bits of the packed update."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd.train import FlatAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 67, 1), (63,), (13, 128, 1), (5,), (1,), (128, 128, 1), (7, 3)]
+    init = [torch.randn(sh, generator=g) for sh in shapes]
+    a_p = [torch.nn.Parameter(p.clone().cuda()) for p in init]
+    b_p = [torch.nn.Parameter(p.clone().cuda()) for p in init]
+    a = FlatAdam(a_p, lr=1e-3, weight_decay=1e-4)
+    b = FlatAdam(b_p, lr=1e-3, weight_decay=1e-4)
+    for step in range(3):
+        grads = [torch.randn(sh, generator=g).cuda() for sh in shapes]
+        if step == 1:
+            grads[3] = None                       # a parameter the loss did not reach
+        flat = torch.cat([(gr if gr is not None else torch.zeros(sh, device="cuda")).reshape(-1)
+                          for gr, sh in zip(grads, shapes)])
+        a.step(flat, grad_scale=0.25)
+        assert b.step_scattered(grads, grad_scale=0.25)
+        assert torch.equal(a.flat, b.flat) and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    assert float(b.state[0]) == 3.0
+
+
 def _dp_worker(rank, world, port, out):
     """One data-parallel rank on the (shared) GPU: gloo process group, captured graphs, own batch."""
     import os
