@@ -303,6 +303,12 @@ int pn2_nll_loss_partials(long long M);
 int pn2_nll_loss(const float *logp, const int64_t *target, const float *weight, long long M, int C,
                  long long ignore_index, double *partial, float *loss, float *wsum, int32_t *err_count,
                  pn2_stream_t stream);
+/* The same in ONE launch: the workgroup that finishes last sums the partials (in index order).  ticket: one device word
+ * the caller zero-initialised once and otherwise leaves alone (the kernel returns it to zero); one launch at a time
+ * per ticket word. */
+int pn2_nll_loss_ticketed(const float *logp, const int64_t *target, const float *weight, long long M, int C,
+                          long long ignore_index, double *partial, float *loss, float *wsum, int32_t *err_count,
+                          unsigned int *ticket, pn2_stream_t stream);
 int pn2_nll_loss_backward(const float *gloss, const int64_t *target, const float *weight, const float *wsum,
                           long long M, int C, long long ignore_index, float *glogp, pn2_stream_t stream);
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pn2_head_logits_backward": [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],
     "pn2_nll_loss_partials": [_cl],
     "pn2_nll_loss": [_vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp, _vp, _vp, _vp],
+    "pn2_nll_loss_ticketed": [_vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_nll_loss_backward": [_vp, _vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp],
     "pn2_adam_step": [_vp, _vp, _vp, _vp, _cl, _vp, _vp, _cd, _cd, _cd, _cd, _cd, _vp],
     "pn2_adam_step_scattered": [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _cd, _cd, _vp],

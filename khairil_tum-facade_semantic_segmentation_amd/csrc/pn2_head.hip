@@ -439,9 +439,11 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
 __global__ __launch_bounds__(256) void nll_partial_kernel(const float *__restrict__ logp, const int64_t *__restrict__ target,
                                                          const float *__restrict__ weight, long long M, int C,
                                                          long long ignore_index, double *__restrict__ partial,
-                                                         int32_t *__restrict__ err_count)
+                                                         int32_t *__restrict__ err_count, unsigned *__restrict__ ticket,
+                                                         float *__restrict__ loss, float *__restrict__ wsum)
 {
     __shared__ double sN[256], sDn[256];
+    __shared__ bool sLast;
     double num = 0.0, den = 0.0;
     int bad = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long long)gridDim.x * 256) {
@@ -461,6 +463,28 @@ __global__ __launch_bounds__(256) void nll_partial_kernel(const float *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sN[0]; partial[2 * blockIdx.x + 1] = sDn[0]; }
+    if (!ticket) return;
+    // With a ticket word the workgroup that finishes last sums the partials (in index order: the same result whoever
+    // is last) -- no second launch.  Release our partial, take a ticket, and as the last one acquire everybody's.
+    if (threadIdx.x == 0) {
+        __threadfence();
+        sLast = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    // all partials in one memory round trip (gridDim.x <= 256 = one per thread), then summed by one thread in index
+    // order from LDS -- the order of nll_finalize_kernel
+    const volatile double *vp = partial;
+    sN[threadIdx.x] = threadIdx.x < gridDim.x ? vp[2 * threadIdx.x] : 0.0;
+    sDn[threadIdx.x] = threadIdx.x < gridDim.x ? vp[2 * threadIdx.x + 1] : 0.0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double n = 0.0, d = 0.0;
+    for (unsigned i = 0; i < gridDim.x; ++i) { n += sN[i]; d += sDn[i]; }
+    *loss = (float)(n / d);                                   // 0/0 -> nan, as torch
+    *wsum = (float)d;
+    *ticket = 0u;                                             // ready for the next launch
 }
 
 __global__ __launch_bounds__(64) void nll_finalize_kernel(const double *__restrict__ partial, int P, float *__restrict__ loss,
@@ -602,8 +626,21 @@ PN2_EXPORT int pn2_nll_loss(const float *logp, const int64_t *target, const floa
     hipStream_t s = (hipStream_t)stream;
     const int P = pn2_nll_loss_partials(M);
     hipLaunchKernelGGL(nll_partial_kernel, dim3(P), dim3(256), 0, s, logp, target, weight, M, C, ignore_index, partial,
-                       err_count);
+                       err_count, static_cast<unsigned *>(nullptr), loss, wsum);
     hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(64), 0, s, partial, P, loss, wsum);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_nll_loss_ticketed(const float *logp, const int64_t *target, const float *weight, long long M, int C,
+                                     long long ignore_index, double *partial, float *loss, float *wsum, int32_t *err_count,
+                                     unsigned int *ticket, pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(logp); PN2_REQUIRE_PTR(target); PN2_REQUIRE_PTR(partial); PN2_REQUIRE_PTR(loss); PN2_REQUIRE_PTR(wsum);
+    PN2_REQUIRE_PTR(ticket);
+    if (M <= 0 || C <= 0) return PN2_ERR_SHAPE;
+    const int P = pn2_nll_loss_partials(M);
+    hipLaunchKernelGGL(nll_partial_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, logp, target, weight, M, C, ignore_index,
+                       partial, err_count, ticket, loss, wsum);
     return PN2_LAUNCH_RC();
 }
 

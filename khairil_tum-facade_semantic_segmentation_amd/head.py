@@ -5,6 +5,8 @@
 
 Rows are per-point ([M, K] features -> [M, C] log-probabilities); torch supplies memory and
 autograd bookkeeping only."""
+import os
+
 import torch
 
 from . import _lib
@@ -81,6 +83,35 @@ def dropout_mask(seed, drop_p, M, K):
     return mask.bool()
 
 
+_tickets = {}
+# PN2_NLL_TICKET=0: the two-launch form of the loss (partials, then a finalize launch) for A/B runs
+_NLL_TICKET = os.environ.get("PN2_NLL_TICKET", "1") == "1"
+
+
+def _ticket_word(dev):
+    """The zeroed device word pn2_nll_loss_ticketed counts finished workgroups in (the kernel returns it to zero).
+    Launches that share a word must be ordered: one word per (device, stream) for eager launches, one per device for
+    launches under stream capture (a graph orders its own nodes; two graphs replaying loss kernels of one device at
+    the same time would need ensure_ticket_words() and their own words -- not a case this package creates)."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev.type, dev.index, "capture" if capturing else torch.cuda.current_stream(dev).cuda_stream)
+    word = _tickets.get(key)
+    if word is None:
+        if capturing:
+            # a word created now would live in the graph's pool and be zero-filled by every replay (one more launch):
+            # still correct; ensure_ticket_words() before the capture avoids it
+            return torch.zeros(1, dtype=torch.int32, device=dev)
+        word = _tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return word
+
+
+def ensure_ticket_words(dev):
+    """Create the device's ticket word for captured launches (call before capturing a graph that holds a loss)."""
+    key = (dev.type, dev.index, "capture")
+    if key not in _tickets and not torch.cuda.is_current_stream_capturing():
+        _tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
 class _NLL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logp, target, weight):
@@ -91,9 +122,14 @@ class _NLL(torch.autograd.Function):
         part = torch.empty((P, 2), dtype=torch.float64, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)           # loss, sum of weights
         with torch.cuda.device(dev):
-            rc = lib.pn2_nll_loss(_ptr(logp), _ptr(target), _ptr(weight), M, C, IGNORE_INDEX, _ptr(part), _ptr(out),
-                                  out.data_ptr() + 4, _ptr(_err_word(dev)), _stream(dev))
-        _lib.check(rc, "pn2_nll_loss")
+            if not _NLL_TICKET:
+                rc = lib.pn2_nll_loss(_ptr(logp), _ptr(target), _ptr(weight), M, C, IGNORE_INDEX, _ptr(part), _ptr(out),
+                                      out.data_ptr() + 4, _ptr(_err_word(dev)), _stream(dev))
+                _lib.check(rc, "pn2_nll_loss")
+        with torch.cuda.device(dev):
+            rc = 0 if not _NLL_TICKET else lib.pn2_nll_loss_ticketed(_ptr(logp), _ptr(target), _ptr(weight), M, C, IGNORE_INDEX, _ptr(part), _ptr(out),
+                                           out.data_ptr() + 4, _ptr(_err_word(dev)), _ptr(_ticket_word(dev)), _stream(dev))
+        _lib.check(rc, "pn2_nll_loss_ticketed")
         _after_fault_op(dev, "nll_loss")
         ctx.save_for_backward(target, weight, out)
         ctx.shape = (M, C)

@@ -10,7 +10,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import mlp
+from . import head, mlp
 
 
 def rotate_z_(blocks_cf, angles=None):
@@ -176,6 +176,7 @@ class SemSegTrainer:
             self.metrics = SegMetrics(ncls, next(model.parameters()).device)
         self._side = torch.cuda.Stream() if self.prefetch else None
         self._prepares = hasattr(model, "prepare_input")        # the pyramid hands the prepared input rows over too
+        self._unit = torch.ones((), dtype=torch.float32, device=next(model.parameters()).device) if on_gpu else None
         self._geo_next = None            # pyramid computed for the coming step
         self._geo_next_src = None        # identity (data_ptr, version, shape) of the batch it was computed from
         self._captured_mode = None       # (exchange, world) the graphs were captured for
@@ -290,7 +291,8 @@ class SemSegTrainer:
         else:
             pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
         loss = self.criterion(pred.reshape(-1, pred.shape[-1]), target.reshape(-1), None, self.class_weight)
-        loss.backward()
+        # the seed of backward is a resident 1.0 (loss.backward() alone fills a fresh ones_like every step: one launch)
+        loss.backward(self._unit if (self._unit is not None and loss.dim() == 0 and loss.dtype == self._unit.dtype) else None)
         if self.metrics is not None:
             self.metrics.add(pred.detach(), target)      # one kernel, no host sync (localfunctions.py:220-223)
         return loss.detach()
@@ -330,6 +332,7 @@ class SemSegTrainer:
     def _capture(self, blocks_cf, target):
         exchange = self._exchange()
         mlp.ensure_momentum_words(self.model)                   # outside the graph: replays then follow set_bn_momentum()
+        head.ensure_ticket_words(blocks_cf.device)
         self._captured_mode = (exchange, self._world())
         self._geo_next_src = self._identity(blocks_cf)          # (prefetch) `cur` will hold this batch's pyramid
         self._static_x = blocks_cf.clone()

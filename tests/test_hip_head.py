@@ -72,6 +72,41 @@ def test_nll_loss(env, M, C, weighted):
     torch.testing.assert_close(ld.grad.cpu().double(), lr.grad, rtol=1e-5, atol=1e-9)
 
 
+def test_nll_loss_single_launch_is_repeatable(env):
+    """The loss is finished by whichever workgroup ends last (pn2_nll_loss_ticketed): launch after launch on the same
+    ticket word, eagerly and replayed from a graph, gives the bits of the two-launch form (fixed summation order)."""
+    torch, head = env
+    from khairil_tum_facade_semantic_segmentation_amd import _lib
+    from khairil_tum_facade_semantic_segmentation_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    M, C = 300000, 13
+    g = torch.Generator().manual_seed(1)
+    logp = torch.log_softmax(torch.randn(M, C, generator=g), dim=1).cuda()
+    t = torch.randint(0, C, (M,), generator=g).cuda()
+    w = (torch.rand(C, generator=g) + 0.5).cuda()
+    P = lib.pn2_nll_loss_partials(M)
+    part = torch.empty((P, 2), dtype=torch.float64, device="cuda")
+    two = torch.empty(2, device="cuda")
+    rc = lib.pn2_nll_loss(_ptr(logp), _ptr(t), _ptr(w), M, C, -100, _ptr(part), _ptr(two), two.data_ptr() + 4, None,
+                          _stream(logp.device))
+    assert rc == 0
+    want = two.clone()
+    for _ in range(20):
+        out = head.nll_loss(logp, t, w)
+        assert float(out) == float(want[0])
+    head.ensure_ticket_words(logp.device)
+    static = torch.zeros((), device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(3):
+            static.copy_(head.nll_loss(logp, t, w))
+    for _ in range(3):
+        static.zero_()
+        graph.replay()
+        assert float(static) == float(want[0])
+    assert all(int(v) == 0 for v in head._tickets.values())
+
+
 def test_nll_loss_bad_target_is_reported(env):
     torch, head = env
     from khairil_tum_facade_semantic_segmentation_amd import ops
