@@ -178,7 +178,8 @@ int pn2_bn_finalize(const float *partial, int P, int C, double count, const floa
  * holds it: pool_max / pool_min [M/32][N] floats, pool_amax / pool_amin [M/32][N] bytes.  The pooled activation is
  * then relu(scale*(scale >= 0 ? zmax : zmin) + shift) (rounding is monotone), chosen by pn2_bn_finalize_out once the
  * batch statistics exist; z is written as usual (the backward reads it) but never re-read by the forward.
- * M % 32 == 0.  PN2_ERR_UNSUPPORTED (nothing launched) when the operands do not allow the pipelined kernels. */
+ * M % 32 == 0.  out = NULL: z is not stored at all (inference: nothing reads it).  PN2_ERR_UNSUPPORTED (nothing launched)
+ * when the operands do not allow the pipelined kernels. */
 int pn2_mlp_gemm_pool32(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int prologue,
                         const float *scale, const float *shift, const float *w, int ldw, const float *bias, float *out,
                         int ldo, int M, int N, float *stat_partial, float *pool_max, float *pool_min,

@@ -108,7 +108,7 @@ __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16
                 csum += z;
                 csq += z * z;
             }
-            ob[(size_t)row * ld] = z;
+            if (!POOL || p.out) ob[(size_t)row * ld] = z;           // pooled inference keeps the extrema only
             if (POOL) {                                              // rows ascend with r: '>' keeps the first
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (z > vmax) { vmax = z; imax = rr; }
@@ -1651,7 +1651,7 @@ static int mlp_gemm_impl(const float *x1, int ld1, int K1, const float *x2, int 
 {
     PN2_REQUIRE_PTR(x1);
     PN2_REQUIRE_PTR(w);
-    PN2_REQUIRE_PTR(out);
+    if (!out && !pool_max) return PN2_ERR_NULL;                 // the pooled epilogue may run without storing z
     if (M < 0 || N <= 0 || K1 <= 0 || K2 < 0 || ld1 < K1) return PN2_ERR_SHAPE;
     if (out2 ? (nsplit <= 0 || nsplit >= N || ldo < nsplit || ldo2 < N - nsplit) : (ldo < N)) return PN2_ERR_SHAPE;
     if (prologue < PRO_NONE || prologue > PRO_BN_BWD) return PN2_ERR_SHAPE;

@@ -94,6 +94,25 @@ def set_bn_momentum(module, momentum):
                 word[1] = float(momentum)
 
 
+def _eval_coefficients(lib, dev, bn, gamma, beta):
+    """scale / shift of an eval-mode BatchNorm.  They depend on frozen tensors only, so they are computed once and kept
+    on the module until one of those tensors changes (in-place version counters, storage, eps): an inference pass over
+    the network launches none of the 22 pn2_bn_eval_coeff kernels again."""
+    key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var)) + (float(bn.eps), str(dev))
+    hit = bn.__dict__.get("_pn2_eval_coeff")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    Co = gamma.shape[0]
+    scale = torch.empty(Co, dtype=torch.float32, device=dev)
+    shift = torch.empty(Co, dtype=torch.float32, device=dev)
+    rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
+                               float(bn.eps), _ptr(scale), _ptr(shift), _stream(dev))
+    _lib.check(rc, "pn2_bn_eval_coeff")
+    if not torch.cuda.is_current_stream_capturing():       # tensors of a graph's pool must not outlive it on a module
+        bn.__dict__["_pn2_eval_coeff"] = (key, scale, shift)
+    return scale, shift
+
+
 class _MLPStack(torch.autograd.Function):
     """y = stack(x1 | x2).  args: bns (list of nn.BatchNorm modules, for running stats / mode),
     pool_k (0 = no pooling), x1 [M,K1], x2 [M,K2] or None, then per layer conv_w, conv_b, bn_w, bn_b."""
@@ -106,6 +125,9 @@ class _MLPStack(torch.autograd.Function):
         M, K1 = x1.shape
         K2 = 0 if x2 is None else x2.shape[1]
         training = bns[0].training
+        # nobody will back-propagate through this call (torch.no_grad() inference): what only the backward reads is not
+        # written
+        inference = not training and not any(ctx.needs_input_grad)
         f32 = dict(dtype=torch.float32, device=dev)
         zs, coefs = [], []
         y = argk = None
@@ -114,7 +136,8 @@ class _MLPStack(torch.autograd.Function):
                 w, b, gamma, beta = params[4 * l:4 * l + 4]
                 Co = w.shape[0]
                 w2 = w.reshape(Co, -1)
-                z = torch.empty((M, Co), **f32)
+                z = None if (inference and l == L - 1 and _FUSED_OUT and pool_k == 32 and Co % 4 == 0 and M % 32 == 0) \
+                    else torch.empty((M, Co), **f32)
                 P = lib.pn2_mlp_gemm_max_partials(M)
                 stat = torch.empty((P, 2, Co), **f32) if training else None
                 last = l == L - 1
@@ -133,10 +156,12 @@ class _MLPStack(torch.autograd.Function):
                     a1, ak1, a2, ak2, pro, psc, psh = src
                     rc = lib.pn2_mlp_gemm_pool32(_ptr(a1), a1.stride(0), ak1, _ptr(a2), 0 if a2 is None else a2.stride(0), ak2,
                                                  pro, _ptr(psc), _ptr(psh), _ptr(w2), w2.stride(0), _ptr(b), _ptr(z),
-                                                 z.stride(0), M, Co, _ptr(stat), _ptr(pooled[0]), _ptr(pooled[1]),
-                                                 _ptr(pooled[2]), _ptr(pooled[3]), _stream(dev))
+                                                 Co if z is None else z.stride(0), M, Co, _ptr(stat), _ptr(pooled[0]),
+                                                 _ptr(pooled[1]), _ptr(pooled[2]), _ptr(pooled[3]), _stream(dev))
                     if rc == _lib.ERR_UNSUPPORTED:      # operands the pipelined kernels do not take: nothing was launched
                         pooled = None
+                        if z is None:
+                            z = torch.empty((M, Co), **f32)
                     else:
                         _lib.check(rc, "pn2_mlp_gemm_pool32")
                 if pooled is None:
@@ -152,8 +177,8 @@ class _MLPStack(torch.autograd.Function):
                     y = torch.empty((rows_out, Co), **f32)
                     argk = torch.empty((rows_out, Co), dtype=torch.uint8, device=dev) if pooled is not None else None
                     pm = pooled or (None, None, None, None)
-                    out_args = (_ptr(z), z.stride(0), _ptr(pm[0]), _ptr(pm[1]), _ptr(pm[2]), _ptr(pm[3]), rows_out, _ptr(y),
-                                _ptr(argk), _stream(dev))
+                    out_args = (_ptr(z), Co if z is None else z.stride(0), _ptr(pm[0]), _ptr(pm[1]), _ptr(pm[2]), _ptr(pm[3]),
+                                rows_out, _ptr(y), _ptr(argk), _stream(dev))
                 if training:
                     mean, invstd = torch.empty(Co, **f32), torch.empty(Co, **f32)
                     mom, mom_dev = momentum_word(bn, dev)
@@ -173,9 +198,7 @@ class _MLPStack(torch.autograd.Function):
                         _lib.check(rc, "pn2_bn_finalize")
                     coefs.append((scale, shift, mean, invstd))
                 else:
-                    rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
-                                               float(bn.eps), _ptr(scale), _ptr(shift), _stream(dev))
-                    _lib.check(rc, "pn2_bn_eval_coeff")
+                    scale, shift = _eval_coefficients(lib, dev, bn, gamma, beta)
                     if out_args is not None:
                         rc = lib.pn2_bn_finalize_out(None, 0, Co, 1.0, None, None, float(bn.eps), 0.0, None, None, None,
                                                      _ptr(scale), _ptr(shift), None, None, None, *out_args)
@@ -185,7 +208,7 @@ class _MLPStack(torch.autograd.Function):
                     coefs.append((scale, shift, bn.running_mean.detach().clone(),
                                   torch.rsqrt(bn.running_var.detach() + bn.eps)))
                 zs.append(z)
-            Co = zs[-1].shape[1]
+            Co = params[4 * (L - 1)].shape[0]
             argk2, k2 = None, 0
             if y is not None:
                 pass                                    # emitted by pn2_bn_finalize_out

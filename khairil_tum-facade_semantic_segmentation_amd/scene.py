@@ -274,20 +274,127 @@ def shard_batches(num_blocks, batch_size, rank=0, world=1):
     return list(range(0, num_blocks, batch_size))[rank::world]
 
 
+class BlockInferencer:
+    """Eval-mode forward passes over fixed-shape sub-batches [B, C, N] as ONE replayed hipGraph: while sub-batch i runs
+    through the MLP stacks, the FPS / ball-query / 3-NN pyramid of sub-batch i+1 (with the first level's grouped rows and
+    the laid-out input) is computed on a parallel branch of the same graph and handed over with one copy -- the scheme of
+    train.SemSegTrainer, forward only.  BatchNorm is frozen (eval), so blocks are independent: a short last sub-batch is
+    padded with copies of its last block.  The graph holds the model's eval coefficients as they were when it was
+    captured: build a new inferencer after changing the weights."""
+
+    def __init__(self, model, batch_size, channels, num_point):
+        import torch
+        self.torch = torch
+        self.model = model.eval()
+        self.dev = next(model.parameters()).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("BlockInferencer replays hipGraphs: the model must live on a HIP device")
+        self.B = int(batch_size)
+        self.cur_x = torch.zeros((self.B, channels, num_point), dtype=torch.float32, device=self.dev)
+        self.next_x = torch.zeros_like(self.cur_x)
+        self._side = torch.cuda.Stream(device=self.dev)
+        self._graph = None
+        self.logp = None
+
+    def _geometry_of(self, x):
+        prepared = self.model.prepare_input(x, None)
+        return self.model.compute_geometry(prepared=prepared, group_first=True) + [prepared[0], prepared[1]]
+
+    def _pack(self, geo):
+        torch = self.torch
+        parts = []
+        for t, pad in zip(geo, self._pads):
+            if t is not None:
+                parts.append(t.contiguous().view(-1).view(torch.uint8))
+            if pad is not None:
+                parts.append(pad)
+        return torch.cat(parts)
+
+    def _capture(self):
+        torch = self.torch
+        with torch.no_grad():
+            for _ in range(2):                                   # lazy initialisations, eval coefficients (cached)
+                self.model(self.cur_x)
+            first = self._geometry_of(self.cur_x)
+            self._pads, off = [], 0
+            for t in first:
+                nbytes = 0 if t is None else t.numel() * t.element_size()
+                pad = (-nbytes) % 16
+                self._pads.append(torch.zeros(pad, dtype=torch.uint8, device=self.dev) if pad else None)
+                off += nbytes + pad
+            self._flat = torch.empty(off, dtype=torch.uint8, device=self.dev)
+            self._flat.copy_(self._pack(first))
+            self._cur, off = [], 0
+            for t, padt in zip(first, self._pads):
+                if t is None:
+                    self._cur.append(None)
+                    continue
+                nbytes = t.numel() * t.element_size()
+                self._cur.append(self._flat[off:off + nbytes].view(t.dtype).view(t.shape))
+                off += nbytes + (0 if padt is None else padt.numel())
+            torch.cuda.synchronize(self.dev)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):              # fork: the next sub-batch's pyramid
+                    new_flat = self._pack(self._geometry_of(self.next_x))
+                geo = self._cur
+                logp, _ = self.model(self.cur_x, geometry=geo[:-2], prepared=(geo[-2], geo[-1]))
+                self.logp = logp
+                self._side.wait_stream(main)                     # the forward no longer reads the current pyramid
+                with torch.cuda.stream(self._side):
+                    self._flat.copy_(new_flat)
+                main.wait_stream(self._side)                     # join
+
+    def run(self, batches, consume):
+        """batches: a sequence of [b, C, N] arrays / tensors, b <= batch_size (channel-first, like the reference's
+        `torch_data.transpose(2, 1)`, localfunctions.py:398); consume(i, logp[:b]) is called for each with the
+        log-probabilities [b, N, classes] -- a view of a static buffer, valid until the next replay is enqueued (enqueue
+        what reads it on the current stream, as VotePool.add does)."""
+        torch = self.torch
+        batches = list(batches)
+        if not batches:
+            return
+        with torch.no_grad():
+            def load(dst, src):
+                src = torch.as_tensor(src, dtype=torch.float32, device=self.dev)
+                b = src.shape[0]
+                dst[:b].copy_(src)
+                if b < self.B:
+                    dst[b:].copy_(src[b - 1:b].expand(self.B - b, -1, -1))
+                return b
+            if self._graph is None:
+                self._capture()
+            load(self.next_x, batches[0])
+            self._flat.copy_(self._pack(self._geometry_of(self.next_x)))   # the first pyramid, on the main stream
+            for i, blocks in enumerate(batches):
+                nxt = batches[i + 1] if i + 1 < len(batches) else blocks
+                b = blocks.shape[0]
+                load(self.next_x, nxt)
+                self._graph.replay()
+                consume(i, self.logp[:b])
+
+
 def infer_scene(model, data_room, index_room, sample_weight, num_points, num_classes, batch_size=32, num_votes=1,
-                retile=None, group=None):
+                retile=None, group=None, graphs=False):
     """Whole-scene voting inference (localfunctions.py:375-405): run the network over the scene's
     blocks in sub-batches, vote on the device, return the per-point predicted label tensor.
     `retile`, if given, is called before every vote round after the first to re-draw the blocks
     (the reference re-tiles per vote, :377; with several ranks it must return the same tiling on every rank).
     Under torch.distributed (one process per GPU) the sub-batches of the scene are sharded over the ranks and the
     int32 vote pools are summed with ONE all-reduce per scene (RCCL over xGMI when the backend is "nccl"); every
-    rank returns the full label tensor."""
+    rank returns the full label tensor.
+    graphs=True (HIP device): the sub-batches run through a BlockInferencer (one replayed graph, the next sub-batch's
+    pyramid prefetched)."""
     import torch
     import torch.distributed as dist
     dev = next(model.parameters()).device
     votes = VotePool(num_points, num_classes, dev)
     model.eval()
+    engine = None
+    if graphs and dev.type == "cuda" and hasattr(model, "compute_geometry"):
+        engine = BlockInferencer(model, batch_size, data_room.shape[2], data_room.shape[1])
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -295,7 +402,16 @@ def infer_scene(model, data_room, index_room, sample_weight, num_points, num_cla
         for v in range(num_votes):
             if v > 0 and retile is not None:
                 data_room, _, sample_weight, index_room = retile()
-            for s in shard_batches(data_room.shape[0], batch_size, rank, world):
+            starts = shard_batches(data_room.shape[0], batch_size, rank, world)
+            if engine is not None:
+                def vote(i, logp, starts=starts, index_room=index_room, sample_weight=sample_weight):
+                    s0 = starts[i]
+                    votes.add(logp=logp, point_idx=torch.as_tensor(index_room[s0:s0 + batch_size], device=dev),
+                              weight=torch.as_tensor(sample_weight[s0:s0 + batch_size], dtype=torch.float32, device=dev))
+                engine.run([torch.as_tensor(data_room[s0:s0 + batch_size], dtype=torch.float32, device=dev).transpose(2, 1)
+                            for s0 in starts], vote)
+                continue
+            for s in starts:
                 x = torch.as_tensor(data_room[s:s + batch_size], dtype=torch.float32, device=dev).transpose(2, 1)
                 logp, _ = model(x)
                 votes.add(logp=logp, point_idx=torch.as_tensor(index_room[s:s + batch_size], device=dev),

@@ -63,3 +63,43 @@ def test_infer_scene_round_trip(orc, synth):
             logp, _ = model(torch.as_tensor(data[s:s + 4], dtype=torch.float32, device=dev).transpose(2, 1))
             pool = so.add_vote(pool, idx[s:s + 4], logp.cpu().max(2)[1].numpy(), wt[s:s + 4])
     assert np.array_equal(pred, np.argmax(pool, 1))
+
+
+def test_block_inferencer_matches_eager_forward(orc, synth, monkeypatch):
+    """The replayed inference graph (next sub-batch's pyramid on a parallel branch, the first level's rows from the
+    fused query launch, cached eval coefficients, no z of the pooled layers) gives the eager eval forward's bits, also
+    for a short last sub-batch; infer_scene(graphs=True) votes like infer_scene()."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd import scene
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+    real_randint = torch.randint
+    monkeypatch.setattr(torch, "randint", lambda low, high, size, **kw: real_randint(0, 1, size, **kw))   # FPS starts
+    K, B, N = 8, 4, 2048
+    dev = torch.device("cuda:0")
+    model = M.get_model(K, 3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(orc.state_shapes(K, 3)).items()})
+    model = model.to(dev).eval()
+    blocks = [synth.draw_case(300 + i, b, N, 9, kind, K)[0] for i, (b, kind) in enumerate(((4, "cube"), (4, "facade"), (3, "cube")))]
+    xs = [torch.from_numpy(np.ascontiguousarray(b.transpose(0, 2, 1))).to(dev) for b in blocks]
+    with torch.no_grad():
+        want = [model(x)[0].clone() for x in xs[:2]]
+        pad = torch.cat([xs[2], xs[2][-1:]])
+        want.append(model(pad)[0][:3].clone())
+    got = []
+    engine = scene.BlockInferencer(model, B, 9, N)
+    engine.run(xs, lambda i, logp: got.append(logp.clone()))
+    engine.run(xs[:1], lambda i, logp: got.append(logp.clone()))          # a second scene through the same graph
+    assert len(got) == 4
+    for a, b in zip(got, want + want[:1]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # whole scene: same votes
+    rs = np.random.RandomState(3)
+    P = 7000
+    xyz = rs.uniform(0, 1, size=(P, 3)) * np.array([1.6, 1.2, 2.5]) + np.array([5.0, 7.0, 0.5])
+    labels = rs.randint(0, K, size=(P,))
+    rgb = [rs.randint(0, 256, size=(P,)).astype(np.float64) for _ in range(3)]
+    np.random.seed(5)
+    data, lab, wt, idx = scene.SceneTiler(xyz, labels, rgb, ["red", "blue", "green"], block_points=N).tile()
+    a = scene.infer_scene(model, data, idx, wt, P, K, batch_size=4)
+    b = scene.infer_scene(model, data, idx, wt, P, K, batch_size=4, graphs=True)
+    assert torch.equal(a, b)
