@@ -47,7 +47,7 @@ class get_model(nn.Module):
         when `angles` [B] is given.  Pass the result as `prepared=` to compute_geometry() / forward()."""
         return ops.input_blocks(xyz, True, angles)
 
-    def compute_geometry(self, xyz=None, prepared=None, group_first=False):
+    def compute_geometry(self, xyz=None, prepared=None, group_first=False, for_backward=True):
         """Everything in the forward pass that depends on the input coordinates only: the FPS /
         ball-query pyramid of the four SA levels and the 3-NN tables of the four FP levels
         (SURVEY.md 3.3).  Returns a flat list of tensors that forward(geometry=...) consumes; it
@@ -56,7 +56,8 @@ class get_model(nn.Module):
         group_first (with `prepared`): the first level's grouped rows [B,S,K,12] too -- its features are the network input,
         so the launch that finds the indices gathers the rows as well (the fused query + group kernel of DESIGN 4.2)
         and forward(geometry=...) starts at the first GEMM; slot [32] of the list (None when the shape is outside the
-        planned path)."""
+        planned path).
+        for_backward=False (inference): the transposed tables that only the atomic-free backward reads are left out."""
         cur = prepared[1] if prepared is not None else xyz.permute(0, 2, 1)[:, :, :3].contiguous()
         levels = [cur]
         out, inv = [], []
@@ -70,13 +71,13 @@ class get_model(nn.Module):
             # A transposed index for the grouping backward is possible too (ops.group_points(inv=...)), but the
             # per-point lists have a heavy tail (a point sits in up to ~100 balls) and the gather-sum is then
             # slower than the scatter-add (measured 88 us against 71 us for levels 2-4): interpolation only.
-            pair = ops.invert_index(idx, levels[-1].shape[1]) if (i > 0 and _INVERT_GROUPING) else None
+            pair = ops.invert_index(idx, levels[-1].shape[1]) if (i > 0 and _INVERT_GROUPING and for_backward) else None
             inv += list(pair) if pair is not None else [None, None]
             levels.append(new_xyz)
         for lvl in (3, 2, 1, 0):
             idx3, w3 = ops.three_nn(levels[lvl], levels[lvl + 1])
             out += [idx3, w3]
-            pair = ops.invert_index(idx3, levels[lvl + 1].shape[1])
+            pair = ops.invert_index(idx3, levels[lvl + 1].shape[1]) if for_backward else None
             inv += list(pair) if pair is not None else [None, None]
         # [0:8] SA, [8:16] FP, [16:24] SA inverses, [24:32] FP inverses, [32] grouped rows of level 1
         return out + inv + ([grouped1] if group_first else [])

@@ -298,17 +298,11 @@ class BlockInferencer:
 
     def _geometry_of(self, x):
         prepared = self.model.prepare_input(x, None)
-        return self.model.compute_geometry(prepared=prepared, group_first=True) + [prepared[0], prepared[1]]
+        return self.model.compute_geometry(prepared=prepared, group_first=True, for_backward=False) + [prepared[0], prepared[1]]
 
     def _pack(self, geo):
-        torch = self.torch
-        parts = []
-        for t, pad in zip(geo, self._pads):
-            if t is not None:
-                parts.append(t.contiguous().view(-1).view(torch.uint8))
-            if pad is not None:
-                parts.append(pad)
-        return torch.cat(parts)
+        from .train import pack_segments
+        return pack_segments(geo, self._pads)
 
     def _capture(self):
         torch = self.torch

@@ -28,6 +28,21 @@ def rotate_z_(blocks_cf, angles=None):
     return blocks_cf
 
 
+def pack_segments(tensors, pads):
+    """The tensors (None = absent) with their zero pads (uint8, None = none) as one uint8 buffer.  Concatenated as
+    32-bit words when every segment allows it: torch's byte-wise cat moves one byte per thread (110 us for the 27 MB of
+    a pyramid with the first level's grouped rows; 4x fewer elements this way)."""
+    parts = []
+    for t, pad in zip(tensors, pads):
+        if t is not None:
+            parts.append(t.contiguous().view(-1).view(torch.uint8))
+        if pad is not None:
+            parts.append(pad)
+    if all(p.numel() % 4 == 0 and p.data_ptr() % 4 == 0 for p in parts):
+        return torch.cat([p.view(torch.int32) for p in parts]).view(torch.uint8)
+    return torch.cat(parts)
+
+
 class FlatGradients:
     """Data-parallel gradient exchange as ONE collective: after backward the per-parameter
     gradients are packed into a contiguous fp32 buffer (one concat kernel, 3.88 MB for
@@ -272,13 +287,7 @@ class SemSegTrainer:
 
     def _pack_geometry(self, geo):
         """The pyramid's tensors as one uint8 buffer (segment layout fixed at capture time)."""
-        parts = []
-        for t, pad in zip(geo, self._geo_pads):
-            if t is not None:
-                parts.append(t.contiguous().view(-1).view(torch.uint8))
-            if pad is not None:
-                parts.append(pad)
-        return torch.cat(parts)
+        return pack_segments(geo, self._geo_pads)
 
     def _forward_backward(self, blocks_cf, target, geometry=None):
         self.grads.zero()
