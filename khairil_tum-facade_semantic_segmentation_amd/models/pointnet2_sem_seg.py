@@ -18,6 +18,9 @@ _INVERT_GROUPING = os.environ.get("PN2_INVERT_GROUPING", "0") == "1"
 _FUSED_DROPOUT = os.environ.get("PN2_FUSED_DROPOUT", "1") == "1"
 # gradients of a level's features (grouping of the next level + skip connection) summed inside the grouping backward
 _SKIP_IN_SCATTER = os.environ.get("PN2_SKIP_IN_SCATTER", "1") == "1"
+# conv1 / bn1 / relu of the head as the last layers of fp1's stack (fp1's activated output is never written, one
+# top-of-stack BatchNorm-backward reduction less); PN2_HEAD_IN_FP1=0: a stack of its own, for A/B runs
+_HEAD_IN_FP1 = os.environ.get("PN2_HEAD_IN_FP1", "1") == "1"
 
 # (npoint, radius, nsample, mlp) per set-abstraction level; reference :9-12
 SA_LEVELS = ((1024, 0.1, 32, (32, 32, 64)), (256, 0.2, 32, (64, 64, 128)),
@@ -116,14 +119,19 @@ class get_model(nn.Module):
         up = feat[4]
         for j, (lvl, fp) in enumerate(zip((3, 2, 1, 0), (self.fp4, self.fp3, self.fp2, self.fp1))):
             pre = None if geometry is None else (geometry[8 + 2 * j], geometry[9 + 2 * j]) + self._inverse(geometry, 4 + j)
-            up = fp.forward_cl(geo[lvl], geo[lvl + 1], feat[lvl] if lvl else None, up, nn=pre)   # :31-34
+            # the head's conv1 -> bn1 -> relu (:36) reads the last level's output and nothing else does: one stack
+            tail = ([self.conv1], [self.bn1]) if (lvl == 0 and _HEAD_IN_FP1 and not _utils._TORCH_MLP) else None
+            up = fp.forward_cl(geo[lvl], geo[lvl + 1], feat[lvl] if lvl else None, up, nn=pre, tail=tail)   # :31-34
         if _utils._TORCH_MLP:                            # A/B switch: the head through torch ops
             h = up.permute(0, 2, 1)
             h = self.drop1(F.relu(self.bn1(self.conv1(h))))  # :36
             h = F.log_softmax(self.conv2(h), dim=1)          # :37-38
             return h.permute(0, 2, 1), feat[4].permute(0, 2, 1)
         B, N, C = up.shape
-        h = _utils._mlp(up.reshape(B * N, C), None, [self.conv1], [self.bn1])   # conv1 -> bn1 -> relu (:36)
+        if _HEAD_IN_FP1:
+            h = up.reshape(B * N, C)                     # conv1 / bn1 / relu ran as the last layers of fp1's stack
+        else:
+            h = _utils._mlp(up.reshape(B * N, C), None, [self.conv1], [self.bn1])   # conv1 -> bn1 -> relu (:36)
         # dropout (:36) inside the head kernels: the keep-mask is regenerated from a device seed, never stored
         p = float(self.drop1.p) if self.training else 0.0
         if p > 0.0 and _FUSED_DROPOUT:

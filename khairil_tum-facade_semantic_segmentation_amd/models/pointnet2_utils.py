@@ -241,9 +241,13 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
             self.mlp_convs.append(nn.Conv1d(ci, co, 1))
             self.mlp_bns.append(nn.BatchNorm1d(co))
 
-    def forward_cl(self, xyz1, xyz2, points1, points2, nn=None):
+    def forward_cl(self, xyz1, xyz2, points1, points2, nn=None, tail=None):
         """Channel-last: xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,D1]|None, points2 [B,S,D2] -> [B,N,C'].
-        `nn` = a precomputed (idx3, weight3[, inverse index]) tuple from ops.three_nn(xyz1, xyz2)."""
+        `nn` = a precomputed (idx3, weight3[, inverse index]) tuple from ops.three_nn(xyz1, xyz2).
+        tail = (convs, bns): further pointwise conv / BatchNorm / ReLU layers of the CALLER that consume this level's
+        output and nothing else does (the segmentation head's conv1 / bn1 after the last level): run as more layers of
+        the same stack -- this level's activated output is then never materialised, and its backward needs no
+        top-of-stack reduction of its own."""
         B, N, _ = xyz1.shape
         S = xyz2.shape[1]
         if S == 1:                                      # :293-294
@@ -253,10 +257,13 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
             inv = nn[2] if nn is not None and len(nn) > 2 else None    # ops.invert_index(idx3, S)
             interpolated = ops.three_interpolate(points2, idx3, w3, inv=inv)   # :303
         D2 = interpolated.shape[-1]
+        convs, bns = list(self.mlp_convs), list(self.mlp_bns)
+        if tail is not None:
+            convs, bns = convs + list(tail[0]), bns + list(tail[1])
         if points1 is None:                             # :305-309 (the concat is never materialised)
-            y = _mlp(interpolated.reshape(B * N, D2), None, self.mlp_convs, self.mlp_bns)
+            y = _mlp(interpolated.reshape(B * N, D2), None, convs, bns)
         else:
-            y = _mlp(points1.reshape(B * N, -1), interpolated.reshape(B * N, D2), self.mlp_convs, self.mlp_bns)
+            y = _mlp(points1.reshape(B * N, -1), interpolated.reshape(B * N, D2), convs, bns)
         return y.reshape(B, N, -1)
 
     def forward(self, xyz1, xyz2, points1, points2):

@@ -301,8 +301,11 @@ EVAL_CASES = (("cube", 9, 18), ("facade", 9, 18), ("cube", 6, 18), ("cube", 9, 8
 
 
 @pytest.mark.parametrize("kind,C,K", EVAL_CASES)
-def test_network_eval_logprobs_within_1e3(pn2, orc, synth, golden, kind, C, K):
+def test_network_eval_logprobs_within_1e3(pn2, orc, synth, golden, kind, C, K, monkeypatch):
     torch = pn2.torch
+    # the per-level taps need fp1's own output: the head's conv1 / bn1 as a stack of its own for this pass (the merged
+    # form is compared with it below)
+    monkeypatch.setattr(pn2.M, "_HEAD_IN_FP1", False)
     g = golden("model_eval_%s_c%d_k%d" % (kind, C, K))
     blocks, _, starts, _ = synth.draw_case(int(g["seed"]), 1, 4096, C, kind, K)
     model = pn2.M.get_model(K, C - 6)
@@ -334,6 +337,13 @@ def test_network_eval_logprobs_within_1e3(pn2, orc, synth, golden, kind, C, K):
             assert np.abs(got - ref)[:, :, ok[0, ::8]].max() <= 1e-3, name
         else:
             assert np.abs(got - ref).max() <= 1e-3, name
+    # conv1 / bn1 / relu as the last layers of fp1's stack (the shipped wiring): the same bits
+    for name in ("sa1", "sa2", "sa3", "sa4", "fp4", "fp3", "fp2", "fp1"):
+        getattr(model, name).__dict__.pop("forward_cl", None)
+    monkeypatch.setattr(pn2.M, "_HEAD_IN_FP1", True)
+    with torch.no_grad(), pn2.U.fps_starts(starts):
+        logp2, l4b = model(dev(pn2, blocks).permute(0, 2, 1))
+    assert torch.equal(logp2, logp) and torch.equal(l4b, l4)
 
 
 @pytest.mark.parametrize("kind,C,K", (("cube", 9, 18), ("facade", 6, 8)))
