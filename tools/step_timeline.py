@@ -2,7 +2,7 @@
 """Timeline of ONE steady-state training step from a rocprofv3 --kernel-trace CSV of bench.py:
     python tools/step_timeline.py <dir with *_kernel_trace.csv> [step_from_end]
 Per queue: every dispatch with its start offset, duration and the gap since the previous dispatch on that queue ended;
-then the sums (busy, gaps) per queue and per kernel name.  The step is delimited by the adam_step_kernel launches."""
+then the sums (busy, gaps) per queue and per kernel name.  The step is delimited by the Adam update launches (adam_step*)."""
 import collections
 import csv
 import glob
@@ -15,7 +15,7 @@ if not files:
 rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r['Kernel_Name']]
+ends = [i for i, r in enumerate(rows) if 'adam_step' in r['Kernel_Name']]
 if len(ends) < back + 1:
     sys.exit("fewer than %d steps in the trace" % (back + 1))
 t0 = int(rows[ends[-back - 1]]['End_Timestamp'])
