@@ -61,6 +61,7 @@ struct GemmArgs {
     // statistics are known (bn_finalize_out_kernel).
     float *pool_max, *pool_min;
     unsigned char *pool_amax, *pool_amin;
+    int store_wt;                 // epilogue stores of the straight-line forward path write through (agent scope)
 };
 
 // Epilogue of one 32x32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half): bias,
@@ -108,7 +109,11 @@ __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16
                 csum += z;
                 csq += z * z;
             }
-            if (!POOL || p.out) ob[(size_t)row * ld] = z;           // pooled inference keeps the extrema only
+            if (!POOL || p.out) {                                    // pooled inference keeps the extrema only
+                // write-through: the rows are read next by another kernel (on any XCD) and the launch would otherwise
+                // end with the write-back of up to 32 MB of dirty L2 lines
+                pn2::store_rows(&ob[(size_t)row * ld], z, p.store_wt & 1);
+            }
             if (POOL) {                                              // rows ascend with r: '>' keeps the first
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (z > vmax) { vmax = z; imax = rr; }
@@ -314,8 +319,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
                     csum[cb] += z;
                     csq[cb] += z * z;
                 }
-                if (p.out2 && col >= p.nsplit) p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] = z;
-                else p.out[(size_t)row * p.ldo + col] = z;
+                pn2::store_rows((p.out2 && col >= p.nsplit) ? &p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] : &p.out[(size_t)row * p.ldo + col], z, p.store_wt & 1);
             }
         }
     }
@@ -553,8 +557,7 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
                                 csum[cb] += z;
                                 csq[cb] += z * z;
                             }
-                            if (p.out2 && col >= p.nsplit) p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] = z;
-                else p.out[(size_t)row * p.ldo + col] = z;
+                            pn2::store_rows((p.out2 && col >= p.nsplit) ? &p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] : &p.out[(size_t)row * p.ldo + col], z, p.store_wt & 1);
                         }
                     }
                 }
@@ -945,6 +948,7 @@ struct BnOutArgs {
     long long rows_out;
     float *y;                       // [rows_out][C]
     unsigned char *argk;            // [rows_out][C], select only
+    int wt;                         // y written through (pn2::store_rows4)
 };
 
 __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOutArgs o)
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOu
             y.y = fmaxf(sc.y * v.y + sh.y, 0.f);
             y.z = fmaxf(sc.z * v.z + sh.z, 0.f);
             y.w = fmaxf(sc.w * v.w + sh.w, 0.f);
-            *reinterpret_cast<float4 *>(o.y + (size_t)r * C + c) = y;
+            pn2::store_rows4(o.y, (size_t)r * C + c, y, o.wt != 0, (size_t)o.rows_out * C * sizeof(float));
         }
     } else {
 #pragma unroll 2
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOu
                         k.f = (y.f > 0.f && sc.f != 0.f) ? (up ? ah.f : al.f) : (unsigned char)0; } while (0)
             PN2_SEL(x); PN2_SEL(y); PN2_SEL(z); PN2_SEL(w);
 #undef PN2_SEL
-            *reinterpret_cast<float4 *>(o.y + e) = y;
+            pn2::store_rows4(o.y, e, y, o.wt != 0, (size_t)o.rows_out * C * sizeof(float));
             *reinterpret_cast<uchar4 *>(o.argk + e) = k;
         }
     }
@@ -1066,6 +1070,7 @@ struct DwArgs {
     const float *ascale, *ashift;   // previous layer's BN coefficients (null: input is already an activation)
     float *partial;                 // [gridDim.x][N][K1+K2+1]
     int M, N;
+    int store_wt;                   // slabs written through (pn2::store_rows)
 };
 
 constexpr int DW_BN = 64, DW_BK = 64, DW_LD = 68;
@@ -1255,7 +1260,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
     const int klim = VEC4 ? Kact : Kout;                         // VEC4: the bias column comes from dbs below
     for (int e = tid; e < 64 * 64; e += MLP_THREADS) {
         const int n = e >> 6, k = e & 63;
-        if (n0 + n < p.N && k0 + k < klim) out[(size_t)(n0 + n) * Kout + k0 + k] = red[n * DW_LD + k];
+        if (n0 + n < p.N && k0 + k < klim) pn2::store_rows(&out[(size_t)(n0 + n) * Kout + k0 + k], red[n * DW_LD + k], p.store_wt & 2);
     }
     if (VEC4 && blockIdx.z == 0) {
         // 16 threads (rb = 0..15) hold partial sums for the same 4 columns: combine through LDS
@@ -1406,7 +1411,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int k = k0 + wk * 64 + b * 32 + l31;
-                if (n < p.N && k < Kact) out[(size_t)n * Kout + k] = acc[a][b][r];
+                if (n < p.N && k < Kact) pn2::store_rows(&out[(size_t)n * Kout + k], acc[a][b][r], p.store_wt & 2);
             }
     if (blockIdx.z == 0) {
         // bias gradient: 8 threads (rb = 0..7) hold partial column sums for the same 4 columns
@@ -1675,6 +1680,7 @@ static int mlp_gemm_impl(const float *x1, int ld1, int K1, const float *x2, int 
     a.stat_partial = stat_partial;
     a.mask_z = mask_z; a.mscale = mscale; a.mshift = mshift; a.mmean = mmean; a.minvstd = minvstd; a.ldm = ldm;
     a.pool_max = pool_max; a.pool_min = pool_min; a.pool_amax = pool_amax; a.pool_amin = pool_amin;
+    a.store_wt = pn2::tune_get("store_wt", 7);
     // float4 staging needs 16-B aligned rows and a concat boundary on a multiple of 4
     bool vec4 = (ld1 % 4 == 0) && aligned16(x1) && (K1 % 4 == 0) && (a.K % 4 == 0);
     if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
@@ -1810,7 +1816,7 @@ PN2_EXPORT int pn2_bn_finalize_out(const float *partial, int P, int C, double co
     a.num_batches_tracked = num_batches_tracked;
     BnOutArgs o;
     o.z = z; o.ldz = ldz; o.pool_max = pool_max; o.pool_min = pool_min; o.pool_amax = pool_amax; o.pool_amin = pool_amin;
-    o.rows_out = rows_out; o.y = y; o.argk = argk;
+    o.rows_out = rows_out; o.y = y; o.argk = argk; o.wt = pn2::tune_get("store_wt", 7) & 4;
     // row slices: 128 rows per pass of a workgroup; at most 64 slices (every slice repeats the finalize)
     long long slices = (rows_out + 127) / 128;
     const long long cap = pn2::tune_get("bn_out_slices", 64);
@@ -1922,6 +1928,7 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     a.g = g; a.z = z; a.ldg = ldg; a.ldz = ldz; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
     a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.x1 = x1; a.x2 = x2; a.ld1 = ld1; a.ld2 = ld2;
     a.K1 = K1; a.K2 = K2; a.ascale = ascale; a.ashift = ashift; a.partial = partial; a.M = M; a.N = N;
+    a.store_wt = pn2::tune_get("store_wt", 7);
     const int K = K1 + K2, P = pn2_mlp_dw_partials(M, N, K);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     dim3 grid((unsigned)P, (unsigned)((N + DW_BN - 1) / DW_BN), (unsigned)((K + 1 + DW_BK - 1) / DW_BK));
