@@ -24,15 +24,14 @@
 #endif
 
 namespace pn2 {
-// A row of a tensor the NEXT kernel reads (on any XCD): written through to memory (agent-scope atomic store = sc1) when
-// `wt`, so that the launch does not end with the write-back of its dirty L2 lines (measured on the MLP stack: 27 us per
-// training step for the forward epilogues alone).
-// The 16-byte form: `dst` = base + a byte offset below 4 GB, through a buffer descriptor (aux 16 = sc1); tensors of 4 GB
-// and more keep plain stores.
+// Rows of a tensor the NEXT kernel reads (on any XCD) are written through to memory -- agent-scope atomic stores / sc1
+// buffer stores -- so that they stream out while the kernel computes instead of leaving the launch to end with the
+// write-back of its dirty L2 lines.  Unconditional on purpose: a run-time switch around the store inside the unrolled
+// epilogues cost 80 us per training step whichever way it was set (the stores were no longer straight-line code).
 typedef int wt_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_rows4(float *base, size_t elem, float4 v, bool wt, size_t total_bytes)
+__device__ __forceinline__ void store_rows4(float *base, size_t elem, float4 v, size_t total_bytes)
 {
-    if (wt && total_bytes < 0xffffff00ull) {
+    if (total_bytes < 0xffffff00ull) {                // uniform; 16-byte form through a buffer descriptor (aux 16 = sc1)
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(unsigned)total_bytes, 0x00020000);
         wt_v4i w;
         w.x = __float_as_int(v.x); w.y = __float_as_int(v.y); w.z = __float_as_int(v.z); w.w = __float_as_int(v.w);
@@ -42,10 +41,9 @@ __device__ __forceinline__ void store_rows4(float *base, size_t elem, float4 v, 
     }
 }
 
-__device__ __forceinline__ void store_rows(float *dst, float v, int wt)
+__device__ __forceinline__ void store_rows(float *dst, float v)
 {
-    if (wt) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *dst = v;
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Developer tuning knob: PN2_TUNE_<NAME>=<int> in the environment overrides a launch heuristic.  The environment

@@ -403,12 +403,12 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
                 float *o = gy + (size_t)(row0 + rb * 32 + 4 * half) * ldgy + col;
                 if (full) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * ldgy] = acc[r];
+                    for (int r = 0; r < 16; ++r) pn2::store_rows(&o[(size_t)((r & 3) + 8 * (r >> 2)) * ldgy], acc[r]);   // read next by the stack's backward
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rl = (r & 3) + 8 * (r >> 2);
-                        if (row0 + rb * 32 + 4 * half + rl < M) o[(size_t)rl * ldgy] = acc[r];
+                        if (row0 + rb * 32 + 4 * half + rl < M) pn2::store_rows(&o[(size_t)rl * ldgy], acc[r]);
                     }
                 }
             }

@@ -97,7 +97,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ src, long long rows_src, int lds, int col0,
                                                          const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
                                                          const float *__restrict__ weight, long long E, int ediv, int B, int Nkeys,
-                                                         int D, float *__restrict__ out, int wt)
+                                                         int D, float *__restrict__ out)
 {
     constexpr int RPB = 256 / LPR;                                 // rows per workgroup
     const int sub = threadIdx.x % LPR;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
             const f32x4u v = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e / ediv) * lds + c);
             acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
         }
-        pn2::store_rows4(out, (size_t)row * D + c, acc, wt != 0, (size_t)B * Nkeys * D * sizeof(float));
+        pn2::store_rows4(out, (size_t)row * D + c, acc, (size_t)B * Nkeys * D * sizeof(float));
     }
 }
 
@@ -198,7 +198,7 @@ PN2_EXPORT int pn2_gather_sum(const float *src, long long rows_src, int lds, int
     const long long blocks = (rows + rpb - 1) / rpb;
     if (blocks > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
 #define PN2_GS(L) hipLaunchKernelGGL(gather_sum_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, \
-                                     offsets, entries, weight, E, ediv, B, Nkeys, D, out, pn2::tune_get("store_wt", 7) & 4)
+                                     offsets, entries, weight, E, ediv, B, Nkeys, D, out)
     if (lpr == 8) PN2_GS(8);
     else if (lpr == 16) PN2_GS(16);
     else if (lpr == 32) PN2_GS(32);

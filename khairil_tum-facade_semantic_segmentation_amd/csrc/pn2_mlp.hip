@@ -61,7 +61,6 @@ struct GemmArgs {
     // statistics are known (bn_finalize_out_kernel).
     float *pool_max, *pool_min;
     unsigned char *pool_amax, *pool_amin;
-    int store_wt;                 // epilogue stores of the straight-line forward path write through (agent scope)
 };
 
 // Epilogue of one 32x32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half): bias,
@@ -112,7 +111,7 @@ __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16
             if (!POOL || p.out) {                                    // pooled inference keeps the extrema only
                 // write-through: the rows are read next by another kernel (on any XCD) and the launch would otherwise
                 // end with the write-back of up to 32 MB of dirty L2 lines
-                pn2::store_rows(&ob[(size_t)row * ld], z, p.store_wt & 1);
+                pn2::store_rows(&ob[(size_t)row * ld], z);
             }
             if (POOL) {                                              // rows ascend with r: '>' keeps the first
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -319,7 +318,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
                     csum[cb] += z;
                     csq[cb] += z * z;
                 }
-                pn2::store_rows((p.out2 && col >= p.nsplit) ? &p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] : &p.out[(size_t)row * p.ldo + col], z, p.store_wt & 1);
+                pn2::store_rows((p.out2 && col >= p.nsplit) ? &p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] : &p.out[(size_t)row * p.ldo + col], z);
             }
         }
     }
@@ -557,7 +556,7 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
                                 csum[cb] += z;
                                 csq[cb] += z * z;
                             }
-                            pn2::store_rows((p.out2 && col >= p.nsplit) ? &p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] : &p.out[(size_t)row * p.ldo + col], z, p.store_wt & 1);
+                            pn2::store_rows((p.out2 && col >= p.nsplit) ? &p.out2[(size_t)row * p.ldo2 + (col - p.nsplit)] : &p.out[(size_t)row * p.ldo + col], z);
                         }
                     }
                 }
@@ -948,7 +947,6 @@ struct BnOutArgs {
     long long rows_out;
     float *y;                       // [rows_out][C]
     unsigned char *argk;            // [rows_out][C], select only
-    int wt;                         // y written through (pn2::store_rows4)
 };
 
 __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOutArgs o)
@@ -972,7 +970,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOu
             y.y = fmaxf(sc.y * v.y + sh.y, 0.f);
             y.z = fmaxf(sc.z * v.z + sh.z, 0.f);
             y.w = fmaxf(sc.w * v.w + sh.w, 0.f);
-            pn2::store_rows4(o.y, (size_t)r * C + c, y, o.wt != 0, (size_t)o.rows_out * C * sizeof(float));
+            pn2::store_rows4(o.y, (size_t)r * C + c, y, (size_t)o.rows_out * C * sizeof(float));
         }
     } else {
 #pragma unroll 2
@@ -988,7 +986,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOu
                         k.f = (y.f > 0.f && sc.f != 0.f) ? (up ? ah.f : al.f) : (unsigned char)0; } while (0)
             PN2_SEL(x); PN2_SEL(y); PN2_SEL(z); PN2_SEL(w);
 #undef PN2_SEL
-            pn2::store_rows4(o.y, e, y, o.wt != 0, (size_t)o.rows_out * C * sizeof(float));
+            pn2::store_rows4(o.y, e, y, (size_t)o.rows_out * C * sizeof(float));
             *reinterpret_cast<uchar4 *>(o.argk + e) = k;
         }
     }
@@ -1070,7 +1068,6 @@ struct DwArgs {
     const float *ascale, *ashift;   // previous layer's BN coefficients (null: input is already an activation)
     float *partial;                 // [gridDim.x][N][K1+K2+1]
     int M, N;
-    int store_wt;                   // slabs written through (pn2::store_rows)
 };
 
 constexpr int DW_BN = 64, DW_BK = 64, DW_LD = 68;
@@ -1260,7 +1257,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
     const int klim = VEC4 ? Kact : Kout;                         // VEC4: the bias column comes from dbs below
     for (int e = tid; e < 64 * 64; e += MLP_THREADS) {
         const int n = e >> 6, k = e & 63;
-        if (n0 + n < p.N && k0 + k < klim) pn2::store_rows(&out[(size_t)(n0 + n) * Kout + k0 + k], red[n * DW_LD + k], p.store_wt & 2);
+        if (n0 + n < p.N && k0 + k < klim) pn2::store_rows(&out[(size_t)(n0 + n) * Kout + k0 + k], red[n * DW_LD + k]);
     }
     if (VEC4 && blockIdx.z == 0) {
         // 16 threads (rb = 0..15) hold partial sums for the same 4 columns: combine through LDS
@@ -1411,7 +1408,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int k = k0 + wk * 64 + b * 32 + l31;
-                if (n < p.N && k < Kact) pn2::store_rows(&out[(size_t)n * Kout + k], acc[a][b][r], p.store_wt & 2);
+                if (n < p.N && k < Kact) pn2::store_rows(&out[(size_t)n * Kout + k], acc[a][b][r]);
             }
     if (blockIdx.z == 0) {
         // bias gradient: 8 threads (rb = 0..7) hold partial column sums for the same 4 columns
@@ -1680,7 +1677,6 @@ static int mlp_gemm_impl(const float *x1, int ld1, int K1, const float *x2, int 
     a.stat_partial = stat_partial;
     a.mask_z = mask_z; a.mscale = mscale; a.mshift = mshift; a.mmean = mmean; a.minvstd = minvstd; a.ldm = ldm;
     a.pool_max = pool_max; a.pool_min = pool_min; a.pool_amax = pool_amax; a.pool_amin = pool_amin;
-    a.store_wt = pn2::tune_get("store_wt", 7);
     // float4 staging needs 16-B aligned rows and a concat boundary on a multiple of 4
     bool vec4 = (ld1 % 4 == 0) && aligned16(x1) && (K1 % 4 == 0) && (a.K % 4 == 0);
     if (x2) vec4 = vec4 && (ld2 % 4 == 0) && aligned16(x2);
@@ -1816,7 +1812,7 @@ PN2_EXPORT int pn2_bn_finalize_out(const float *partial, int P, int C, double co
     a.num_batches_tracked = num_batches_tracked;
     BnOutArgs o;
     o.z = z; o.ldz = ldz; o.pool_max = pool_max; o.pool_min = pool_min; o.pool_amax = pool_amax; o.pool_amin = pool_amin;
-    o.rows_out = rows_out; o.y = y; o.argk = argk; o.wt = pn2::tune_get("store_wt", 7) & 4;
+    o.rows_out = rows_out; o.y = y; o.argk = argk;
     // row slices: 128 rows per pass of a workgroup; at most 64 slices (every slice repeats the finalize)
     long long slices = (rows_out + 127) / 128;
     const long long cap = pn2::tune_get("bn_out_slices", 64);
@@ -1928,7 +1924,6 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     a.g = g; a.z = z; a.ldg = ldg; a.ldz = ldz; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
     a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.x1 = x1; a.x2 = x2; a.ld1 = ld1; a.ld2 = ld2;
     a.K1 = K1; a.K2 = K2; a.ascale = ascale; a.ashift = ashift; a.partial = partial; a.M = M; a.N = N;
-    a.store_wt = pn2::tune_get("store_wt", 7);
     const int K = K1 + K2, P = pn2_mlp_dw_partials(M, N, K);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     dim3 grid((unsigned)P, (unsigned)((N + DW_BN - 1) / DW_BN), (unsigned)((K + 1 + DW_BK - 1) / DW_BK));

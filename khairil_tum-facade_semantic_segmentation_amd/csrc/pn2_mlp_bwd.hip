@@ -32,7 +32,6 @@ struct BwdArgs {
     float *stat_partial;                // [grid][2][K] (nullable)
     float *dw_partial;                  // [grid][N][K+1]
     int M, N, K;
-    int store_wt;                 // bit 0: gp rows, bit 1: dW slabs written through (see pn2::store_rows)
 };
 
 template <int NBLK, int KBLK, bool POOLED>
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
                             cs += v;
                             cq += v * ((zp - xmu[i]) * xis[i]);
                         }
-                        if (row0 + rl < p.M && col < p.K) pn2::store_rows(&p.gp[(size_t)(row0 + rl) * p.ldgp + col], v, p.store_wt & 1);
+                        if (row0 + rl < p.M && col < p.K) pn2::store_rows(&p.gp[(size_t)(row0 + rl) * p.ldgp + col], v);
                     }
                     csum[i] += cs;
                     csq[i] += cq;
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (n < p.N && k < p.K) pn2::store_rows(&slab[(size_t)n * Kout + k], accW[i][r], p.store_wt & 2);
+                if (n < p.N && k < p.K) pn2::store_rows(&slab[(size_t)n * Kout + k], accW[i][r]);
             }
         }
     }
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
                         cs += v;
                         cq += v * ((zp - xmu) * xis);
                     }
-                    if (row0 + rl < p.M && col < p.K) pn2::store_rows(&p.gp[(size_t)(row0 + rl) * p.ldgp + col], v, p.store_wt & 1);
+                    if (row0 + rl < p.M && col < p.K) pn2::store_rows(&p.gp[(size_t)(row0 + rl) * p.ldgp + col], v);
                 }
                 csum += cs;
                 csq += cq;
@@ -506,7 +505,7 @@ __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (n < p.N && col < p.K) pn2::store_rows(&slab[(size_t)n * Kout + col], accW[r], p.store_wt & 2);
+                if (n < p.N && col < p.K) pn2::store_rows(&slab[(size_t)n * Kout + col], accW[r]);
             }
         }
         if (dx_wave) {
@@ -753,7 +752,7 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
                                 cs += v;
                                 cq += v * ((zp - xmu[i]) * xis[i]);
                             }
-                            if (row0 + rl < p.M && col < p.K) pn2::store_rows(&p.gp[(size_t)(row0 + rl) * p.ldgp + col], v, p.store_wt & 1);
+                            if (row0 + rl < p.M && col < p.K) pn2::store_rows(&p.gp[(size_t)(row0 + rl) * p.ldgp + col], v);
                         }
                         csum[i] += cs;
                         csq[i] += cq;
@@ -801,7 +800,7 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (n < p.N && k < p.K) pn2::store_rows(&slab[(size_t)n * Kout + k], accW[i][r], p.store_wt & 2);
+                    if (n < p.N && k < p.K) pn2::store_rows(&slab[(size_t)n * Kout + k], accW[i][r]);
                 }
             }
         }
@@ -1030,7 +1029,6 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     a.g = g; a.z = z; a.ldg = ldg; a.ldz = ldz; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
     a.c1 = c1; a.c2 = c2; a.argk = argk; a.pool_k = pool_k; a.w = w; a.ldw = ldw; a.x = x; a.ldx = ldx;
     a.ascale = ascale; a.ashift = ashift; a.amean = amean; a.ainvstd = ainvstd; a.gp = gp; a.ldgp = ldgp;
-    a.store_wt = pn2::tune_get("store_wt", 7);
     a.stat_partial = stat_partial; a.dw_partial = dw_partial; a.M = M; a.N = N; a.K = K;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int nblk = fb_blocks(N), kblk = fb_blocks(K > 128 ? 128 : K);

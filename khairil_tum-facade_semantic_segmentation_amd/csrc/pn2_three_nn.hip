@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
 template <int VEC>
 __global__ __launch_bounds__(256) void three_interpolate_kernel(
     const float *__restrict__ points2, const int64_t *__restrict__ idx3, const float *__restrict__ weight3,
-    long long total, int N, int S, int D, float *__restrict__ out, int wt)
+    long long total, int N, int S, int D, float *__restrict__ out)
 {
     const int dv = D / VEC;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(
             r.y = (a.y * w0 + bb.y * w1) + cc.y * w2;
             r.z = (a.z * w0 + bb.z * w1) + cc.z * w2;
             r.w = (a.w * w0 + bb.w * w1) + cc.w * w2;
-            pn2::store_rows4(out, (size_t)row * D + c, r, wt != 0, (size_t)total * VEC * sizeof(float));   // read next by a GEMM
+            pn2::store_rows4(out, (size_t)row * D + c, r, (size_t)total * VEC * sizeof(float));   // read next by a GEMM
         } else {
             o[0] = (p0[0] * w0 + p1[0] * w1) + p2[0] * w2;
         }
@@ -202,11 +202,11 @@ PN2_EXPORT int pn2_three_interpolate(const float *points2, const int64_t *idx3, 
     if (vec4) {
         const long long total = (long long)B * N * (D / 4);
         hipLaunchKernelGGL(three_interpolate_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, stream, points2,
-                           idx3, weight3, total, N, S, D, out, pn2::tune_get("store_wt", 7) & 4);
+                           idx3, weight3, total, N, S, D, out);
     } else {
         const long long total = (long long)B * N * D;
         hipLaunchKernelGGL(three_interpolate_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, stream, points2,
-                           idx3, weight3, total, N, S, D, out, pn2::tune_get("store_wt", 7) & 4);
+                           idx3, weight3, total, N, S, D, out);
     }
     return PN2_LAUNCH_RC();
 }
