@@ -69,7 +69,7 @@ struct GemmArgs {
 // < M (FULL) stores in straight-line code: vmcnt counts stores too on gfx9, and with a load result first used
 // inside per-row branches the compiler puts s_waitcnt vmcnt(0) in front of every store, i.e. one store
 // acknowledgement round trip per row (16 per block).
-template <bool FULL, bool BWD, bool POOL = false>
+template <bool FULL, bool BWD, int POOL = 0>       // POOL 1: record the group extrema; 2: ... and do not store z (inference)
 __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16 &acc, int row0, int half, int col,
                                                  float &csum, float &csq)
 {
@@ -108,7 +108,7 @@ __device__ __forceinline__ void gemm_store_block(const GemmArgs &p, const f32x16
                 csum += z;
                 csq += z * z;
             }
-            if (!POOL || p.out) {                                    // pooled inference keeps the extrema only
+            if (POOL != 2) {                                         // compile-time: the stores stay straight-line code
                 // write-through: the rows are read next by another kernel (on any XCD) and the launch would otherwise
                 // end with the write-back of up to 32 MB of dirty L2 lines
                 pn2::store_rows(&ob[(size_t)row * ld], z);
@@ -143,7 +143,8 @@ __device__ __forceinline__ void gemm_store_block_any(const GemmArgs &p, const f3
         if (full) gemm_store_block<true, true>(p, acc, row0, half, col, csum, csq);
         else gemm_store_block<false, true>(p, acc, row0, half, col, csum, csq);
     } else {
-        if (full && p.pool_max) gemm_store_block<true, false, true>(p, acc, row0, half, col, csum, csq);
+        if (full && p.pool_max && p.out) gemm_store_block<true, false, 1>(p, acc, row0, half, col, csum, csq);
+        else if (full && p.pool_max) gemm_store_block<true, false, 2>(p, acc, row0, half, col, csum, csq);
         else if (full) gemm_store_block<true, false>(p, acc, row0, half, col, csum, csq);
         else gemm_store_block<false, false>(p, acc, row0, half, col, csum, csq);
     }
