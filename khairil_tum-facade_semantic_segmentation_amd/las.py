@@ -6,7 +6,8 @@ The reference reads scenes with `laspy.read` and uses `las.x / las.y / las.z`,
 practice (sem_seg_training.py:137-156, sem_seg_testing.py:133-141).  laspy is not installable in
 an offline image, so this module parses the public header block and the fixed part of point
 record formats 0-10 itself.  It is NOT pinned against laspy or against TUM-Facade files (neither is
-available here): tests cover a write/read round trip and the header arithmetic only.
+available here): tests read files packed field by field from the specification's tables (independent of
+write_las), and cover write/read round trips and the header arithmetic.
 """
 import struct
 

@@ -52,3 +52,72 @@ def test_las14_formats_and_extra_bytes_round_trip(tmp_path):
             assert d.red is None
         else:
             assert np.array_equal(d.red, rgb[:, 0]) and np.array_equal(d.green, rgb[:, 1]) and np.array_equal(d.blue, rgb[:, 2])
+
+
+def _spec_header(version_minor, point_format, record_len, n, scale, offset, mins, maxs, vlr_bytes=0):
+    """The public header block packed field by field from the ASPRS LAS specification (1.2: 227 bytes; 1.4 R15: 375
+    bytes) -- written here independently of las.write_las, so that read_las is checked against the published layout and
+    not only against its own writer."""
+    import struct
+    hsize = 227 if version_minor < 4 else 375
+    h = b"LASF"                                            # file signature
+    h += struct.pack("<HH", 0, 0)                          # file source id, global encoding
+    h += bytes(16)                                         # project GUID
+    h += struct.pack("<BB", 1, version_minor)              # version
+    h += b"spec-test".ljust(32, b"\0") + b"hand packed".ljust(32, b"\0")    # system identifier, generating software
+    h += struct.pack("<HH", 1, 2024)                       # creation day of year, year
+    h += struct.pack("<H", hsize)                          # header size
+    h += struct.pack("<I", hsize + vlr_bytes)              # offset to point data
+    h += struct.pack("<I", 1 if vlr_bytes else 0)          # number of VLRs
+    h += struct.pack("<BH", point_format, record_len)      # point data record format, record length
+    legacy_n = n if point_format < 6 else 0
+    h += struct.pack("<I", legacy_n)                       # legacy number of point records
+    h += struct.pack("<5I", legacy_n, 0, 0, 0, 0)          # legacy number of points by return
+    h += struct.pack("<3d", *scale) + struct.pack("<3d", *offset)
+    h += struct.pack("<6d", maxs[0], mins[0], maxs[1], mins[1], maxs[2], mins[2])
+    if version_minor >= 4:
+        h += struct.pack("<QQI", 0, 0, 0)                  # start of waveform data, first EVLR, number of EVLRs
+        h += struct.pack("<Q", n)                          # number of point records
+        h += struct.pack("<15Q", n, *([0] * 14))           # number of points by return
+    assert len(h) == hsize
+    return h
+
+
+def test_reader_against_spec_packed_files(tmp_path):
+    """LAS 1.2 format 2 (26-byte records) behind a VLR, and LAS 1.4 format 7 (36-byte records) with 4 extra bytes per
+    record: headers and records packed per the specification's tables; read_las must return the scaled coordinates,
+    classifications and colours."""
+    import struct
+    from khairil_tum_facade_semantic_segmentation_amd import las
+    rs = np.random.RandomState(4)
+    n = 57
+    scale, offset = (0.001, 0.002, 0.01), (690000.0, 5330000.0, 500.0)
+    X = rs.randint(-2 ** 20, 2 ** 20, size=(n, 3)).astype(np.int32)
+    cls = rs.randint(0, 19, size=n).astype(np.uint8)
+    rgb = rs.randint(0, 65536, size=(n, 3)).astype(np.uint16)
+    want = X.astype(np.float64) * np.array(scale) + np.array(offset)
+    mins, maxs = want.min(0), want.max(0)
+
+    # ---- LAS 1.2, point format 2: X Y Z i32, intensity u16, return/flags byte, classification u8, scan angle i8,
+    #      user data u8, point source id u16, red green blue u16
+    vlr = b"\0\0" + b"LASF_Projection".ljust(16, b"\0") + struct.pack("<HH", 34735, 8) + bytes(32) + bytes(8)   # 54 + 8
+    body = b"".join(struct.pack("<iiiHBBbBHHHH", X[i, 0], X[i, 1], X[i, 2], 1000 + i, 0x09, int(cls[i]), -3, 7, 42,
+                                int(rgb[i, 0]), int(rgb[i, 1]), int(rgb[i, 2])) for i in range(n))
+    p12 = tmp_path / "spec12.las"
+    p12.write_bytes(_spec_header(2, 2, 26, n, scale, offset, mins, maxs, vlr_bytes=len(vlr)) + vlr + body)
+    d = las.read_las(str(p12))
+    assert np.array_equal(d.xyz(), want)
+    assert np.array_equal(d.classification, cls)
+    assert np.array_equal(np.stack([d.red, d.green, d.blue], 1), rgb)
+
+    # ---- LAS 1.4, point format 7 (+ 4 extra bytes): X Y Z i32, intensity u16, returns byte, flags byte,
+    #      classification u8, user data u8, scan angle i16, point source id u16, GPS time f64, red green blue u16
+    body = b"".join(struct.pack("<iiiHBBBBhHdHHH", X[i, 0], X[i, 1], X[i, 2], 7, 0x11, 0x00, int(cls[i]), 0, -120, 3,
+                                1.5e8 + i, int(rgb[i, 0]), int(rgb[i, 1]), int(rgb[i, 2])) + b"\xab\xcd\xef\x01"
+                    for i in range(n))
+    p14 = tmp_path / "spec14.las"
+    p14.write_bytes(_spec_header(4, 7, 40, n, scale, offset, mins, maxs) + body)
+    d = las.read_las(str(p14))
+    assert np.array_equal(d.xyz(), want)
+    assert np.array_equal(d.classification, cls)
+    assert np.array_equal(np.stack([d.red, d.green, d.blue], 1), rgb)
