@@ -71,6 +71,14 @@ int pn2_ball_query_group(double radius, int nsample, const float *xyz, const flo
                          const float *points, int B, int N, int S, int D, int64_t *idx, float *grouped,
                          int ldg, int32_t *err_count, pn2_stream_t stream);
 
+/* pn2_ball_query_group through ONE named kernel of the library (parity tests compare every shipped kernel with the
+ * oracle; benchmarks compare them with each other): which = 0 the library's choice (= pn2_ball_query_group),
+ * 1 cell-pruned (pn2_ball_grid.hip), 2 vector-unit scan (pn2_ball_group.hip).
+ * PN2_ERR_UNSUPPORTED (nothing launched) when the named kernel does not take the operands. */
+int pn2_ball_query_group_select(int which, double radius, int nsample, const float *xyz, const float *new_xyz,
+                                const float *points, int B, int N, int S, int D, int64_t *idx, float *grouped,
+                                int ldg, int32_t *err_count, pn2_stream_t stream);
+
 /* ---- planned form of the two entries above (sample_and_group, models/pointnet2_utils.py:110-138) ------------
  * Everything of query_ball_point that depends on the block's geometry only is prepared once per block in a
  * caller-owned workspace `plans` (B * pn2_ball_plan_bytes(N, S, D) bytes, 128-byte aligned; layout in
@@ -348,6 +356,27 @@ int pn2_add_vote(const float *logp, const int64_t *pred_label, const int64_t *po
  * pn2_seg_metrics: accuracy / IoU bookkeeping of a batch (localfunctions.py:214, 220-223, 271-283) added to
  * int64 device counters [2 + 3*C]: [0] correct, [1] seen, [2+c] label == c, [2+C+c] pred == c && label == c,
  * [2+2C+c] pred == c || label == c; pred = arg-max of the row of logp [M][C] (first maximum wins).  C <= 64. */
+/* Sliding-window tiler of whole-scene inference: TestCustomDataset.__getitem__ (sem_seg_testing.py:182-254) on a scene
+ * resident on the device, bucketed like pn2_sample_blocks' (order / cell_start over an nx x ny grid of `cell`-sized
+ * cells with origin x0, y0).
+ * pn2_tile_windows: for each of W closed windows [xmin, xmax] x [ymin, ymax] (windows [W][4] doubles, padding included;
+ *   the np.where of :202-203) either the number of points inside (members == NULL: counts [W]) or the points themselves
+ *   (members + member_off[w], in a deterministic order: grid rows in order, cell order inside a row).
+ * pn2_tile_fill: the blocks of all windows.  Window w owns blocks block_off[w] .. block_off[w+1] (ceil(count / block_points)
+ *   of them, :205-206); its slots take the members plus a random top-up of the members (without replacement while the
+ *   top-up is at most the population, :209-210), in random order (:212) -- keyed pseudo-random permutations of `seed`,
+ *   or, with srcpos [slots], the member position given per slot (the caller replays numpy's choice / shuffle stream:
+ *   bit-identical blocks).  data [blocks][block_points][6+E] = [x - cx, y - cy, z, xyz / coord_max, extra] (:214-239,
+ *   double arithmetic rounded to float once), labels, labelweights[label] (NULL: 1) and the point indices. */
+int pn2_tile_windows(const double *xyz, const int *order, const int *cell_start, double x0, double y0, double cell, int nx,
+                     int ny, const double *windows, int W, const long long *member_off, int *counts, int *members,
+                     pn2_stream_t stream);
+int pn2_tile_fill(const double *xyz, const float *extra, const long long *labels, const float *labelweights, int P, int E,
+                  int num_classes, const double *coord_max, const int *members, const long long *member_off,
+                  const int *counts, const double *centre, const long long *block_off, int W, long long blocks,
+                  int block_points, const int *srcpos, unsigned long long seed, float *data, long long *out_labels,
+                  float *out_weight, long long *out_index, pn2_stream_t stream);
+
 /* pn2_sample_blocks: TrainCustomDataset.__getitem__ (sem_seg_training.py:200-259) for B blocks of one scene that
  * lives on the device: xyz [P][3] double; order [P] / cell_start [nx*ny+1] = the points bucketed into a 2-D grid of
  * `cell`-sized cells from (x0, y0), row-major, ascending index inside a cell; extra [E][P] (nullable) the extra

@@ -17,6 +17,7 @@ SIGNATURES = {
     "pn2_farthest_point_sample": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_square_distance": [_vp, _vp, _ci, _ci, _ci, _vp, _vp],
     "pn2_ball_query_group": [_cd, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp],
+    "pn2_ball_query_group_select": [_ci, _cd, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp],
     "pn2_farthest_point_sample_plan": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _cd, _ci, _vp, _vp, _vp],
     "pn2_ball_plan_bytes": [_ci, _ci, _ci],
     "pn2_ball_pack_rows": [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp],
@@ -65,6 +66,9 @@ SIGNATURES = {
     "pn2_adam_step_scattered": [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _cd, _cd, _vp],
     "pn2_sample_blocks": [_vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _ci, _ci, _ci, _ci, _cd, ctypes.POINTER(ctypes.c_double), _ci, _ci,
                           ctypes.c_ulonglong, _ci, _vp, _vp, _vp, _vp, _vp],
+    "pn2_tile_windows": [_vp, _vp, _vp, _cd, _cd, _cd, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp],
+    "pn2_tile_fill": [_vp, _vp, _vp, _vp, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp, _vp, _vp, _ci, _cl, _ci, _vp,
+                      ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp],
     "pn2_input_blocks": [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "pn2_seg_metrics": [_vp, _vp, _cl, _ci, _vp, _vp],
     "pn2_add_vote": [_vp, _vp, _vp, _vp, _cl, _ci, _cl, _vp, _vp, _vp],

@@ -31,19 +31,42 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, save_temps=False, verbose=False):
+def _compile_one(args):
+    cmd, cwd = args
+    subprocess.check_call(cmd, cwd=cwd)
+
+
+def build(force=False, save_temps=False, verbose=False, jobs=None):
+    """One object per source (rebuilt only when the source or a header is newer), compiled in parallel, then one link."""
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(REPO, "include"), "-I", CSRC]
+    objdir = os.path.join(PKG, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", "-I", os.path.join(REPO, "include"), "-I", CSRC]
+    cwd = PKG
     if save_temps:
-        tmp = os.path.join(PKG, "build", "temps")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-    cmd += sources() + ["-o", LIB]
+        cwd = os.path.join(PKG, "build", "temps")
+        os.makedirs(cwd, exist_ok=True)
+        base += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(REPO, "include", "*.h"))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or save_temps or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            todo.append((base + [src, "-o", obj], cwd))
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=os.path.join(PKG, "build", "temps") if save_temps else PKG)
+        for cmd, _ in todo:
+            print(" ".join(cmd))
+    with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as pool:
+        list(pool.map(_compile_one, todo))
+    link = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden"] + objs + ["-o", LIB]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=PKG)
     return LIB
 
 

@@ -15,9 +15,6 @@
 #include "pn2_common.h"
 
 namespace pn2 {
-int launch_ball_query_mfma(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
-                           int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
-                           hipStream_t stream);
 int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
                            int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
                            hipStream_t stream);
@@ -373,9 +370,14 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
 
 }  // namespace
 
-PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz, const float *new_xyz,
-                                    const float *points, int B, int N, int S, int D, int64_t *idx,
-                                    float *grouped, int ldg, int32_t *err_count, pn2_stream_t stream_)
+// which: 0 = the library's choice; 1 = cell-pruned (pn2_ball_grid.hip); 2 = the vector-unit scan of this file.
+// (A matrix-core kernel -- the exact expression as a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 -- was
+// withdrawn in round 3: at the one shape the dispatch still gave it, SA2's 1024-point blocks, the scan below is faster
+// (7.1 against 12.3 us), and its sign-bit membership test dropped NaN points, which the reference keeps.)  A kernel that does not take the operands
+// returns PN2_ERR_UNSUPPORTED (nothing launched) when it was asked for by number.
+static int ball_query_group_dispatch(int which, double radius, int nsample, const float *xyz, const float *new_xyz,
+                                     const float *points, int B, int N, int S, int D, int64_t *idx, float *grouped, int ldg,
+                                     int32_t *err_count, pn2_stream_t stream_)
 {
     PN2_REQUIRE_PTR(xyz);
     PN2_REQUIRE_PTR(new_xyz);
@@ -385,30 +387,22 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
     if (nsample > 64) return PN2_ERR_UNSUPPORTED;
     if (ldg == 0) ldg = 3 + D;
     if (ldg < 3 + D) return PN2_ERR_SHAPE;
+    if (which < 0 || which > 2) return PN2_ERR_UNSUPPORTED;
     if (B == 0) return PN2_OK;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // Many centroids per block: the waves of a workgroup share one LDS image of the block and
-    // each takes several centroids.  Few centroids (deep levels): small workgroups, two
-    // centroids per wave, for parallelism.
     const long long total = (long long)B * S;
     // Many centroids over a large block that fits LDS: cell-pruned candidates (pn2_ball_grid.hip).
-    if (total >= 4096 && N >= pn2::tune_get("bq_grid_minn", 2048) && pn2::tune_get("bq_grid", 1)) {
+    if (which == 1 || (which == 0 && total >= 4096 && N >= pn2::tune_get("bq_grid_minn", 2048) && pn2::tune_get("bq_grid", 1))) {
         const int rc = pn2::launch_ball_query_grid(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped,
                                                    err_count, stream);
-        if (rc != PN2_ERR_UNSUPPORTED) return rc;
-    }
-    // Many centroids over a block that fits LDS: the matrix-core kernel (pn2_ball_mfma.hip).
-    if (total >= 4096 && pn2::tune_get("bq_mfma", 1)) {
-        const int rc = pn2::launch_ball_query_mfma(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped,
-                                                   err_count, stream);
-        if (rc != PN2_ERR_UNSUPPORTED) return rc;
+        if (rc != PN2_ERR_UNSUPPORTED || which == 1) return rc;
     }
     const int cfg = pn2::tune_get("bq_cfg", total >= 8192 ? 3 : (total >= 2048 ? 1 : 2));
     // Few centroids with wide rows (deep levels): the gather is latency-bound inside the scan
     // waves, so the scan kernel writes idx only and a fully parallel elementwise kernel groups.
     if (grouped && total < 2048 && pn2::tune_get("bq_split", 1)) {
-        int rc = pn2_ball_query_group(radius, nsample, xyz, new_xyz, nullptr, B, N, S, 0, idx, nullptr, 0, err_count, stream_);
+        int rc = ball_query_group_dispatch(2, radius, nsample, xyz, new_xyz, nullptr, B, N, S, 0, idx, nullptr, 0, err_count, stream_);
         if (rc != PN2_OK) return rc;
         return pn2_group_points(xyz, new_xyz, points, idx, B, N, S, nsample, D, grouped, ldg, nullptr, stream_);
     }
@@ -425,4 +419,18 @@ PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz
         default: return PN2_ERR_UNSUPPORTED;
     }
 #undef PN2_BQ
+}
+
+PN2_EXPORT int pn2_ball_query_group(double radius, int nsample, const float *xyz, const float *new_xyz,
+                                    const float *points, int B, int N, int S, int D, int64_t *idx,
+                                    float *grouped, int ldg, int32_t *err_count, pn2_stream_t stream_)
+{
+    return ball_query_group_dispatch(0, radius, nsample, xyz, new_xyz, points, B, N, S, D, idx, grouped, ldg, err_count, stream_);
+}
+
+PN2_EXPORT int pn2_ball_query_group_select(int which, double radius, int nsample, const float *xyz, const float *new_xyz,
+                                           const float *points, int B, int N, int S, int D, int64_t *idx,
+                                           float *grouped, int ldg, int32_t *err_count, pn2_stream_t stream_)
+{
+    return ball_query_group_dispatch(which, radius, nsample, xyz, new_xyz, points, B, N, S, D, idx, grouped, ldg, err_count, stream_);
 }

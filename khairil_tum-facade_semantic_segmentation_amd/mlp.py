@@ -94,23 +94,53 @@ def set_bn_momentum(module, momentum):
                 word[1] = float(momentum)
 
 
+# The tensors an eval-mode BatchNorm's coefficients derive from are updated through RAW POINTERS (pn2_bn_finalize* write
+# running_mean / running_var, pn2_adam_step* write gamma / beta through FlatAdam.flat, hipGraph replays do both): none of
+# that bumps a version counter.  Every such writer bumps this generation instead, and a cached pair is valid for one
+# generation only.
+_generation = [0]
+
+
+def invalidate_eval_coefficients():
+    """Parameters or BatchNorm buffers were (or may have been) written behind torch's back: cached eval coefficients are
+    stale.  Called by every training-mode stack forward, by FlatAdam and by SemSegTrainer.step."""
+    _generation[0] += 1
+
+
 def _eval_coefficients(lib, dev, bn, gamma, beta):
-    """scale / shift of an eval-mode BatchNorm.  They depend on frozen tensors only, so they are computed once and kept
-    on the module until one of those tensors changes (in-place version counters, storage, eps): an inference pass over
-    the network launches none of the 22 pn2_bn_eval_coeff kernels again."""
-    key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var)) + (float(bn.eps), str(dev))
+    """scale / shift of an eval-mode BatchNorm.  Computed once per generation (see above) and kept on the module: an
+    inference pass over the network launches none of the 22 pn2_bn_eval_coeff kernels again.  A stale pair is recomputed
+    INTO THE SAME TENSORS, so a captured graph that reads them (scene.BlockInferencer) sees the refreshed values after
+    refresh_eval_coefficients()."""
+    key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var)) + \
+        (float(bn.eps), str(dev), _generation[0])
     hit = bn.__dict__.get("_pn2_eval_coeff")
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     Co = gamma.shape[0]
-    scale = torch.empty(Co, dtype=torch.float32, device=dev)
-    shift = torch.empty(Co, dtype=torch.float32, device=dev)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if hit is not None and not capturing and hit[1].shape[0] == Co and hit[1].device == dev:
+        scale, shift = hit[1], hit[2]
+    else:
+        scale = torch.empty(Co, dtype=torch.float32, device=dev)
+        shift = torch.empty(Co, dtype=torch.float32, device=dev)
     rc = lib.pn2_bn_eval_coeff(Co, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                                float(bn.eps), _ptr(scale), _ptr(shift), _stream(dev))
     _lib.check(rc, "pn2_bn_eval_coeff")
-    if not torch.cuda.is_current_stream_capturing():       # tensors of a graph's pool must not outlive it on a module
+    if not capturing:                                      # tensors of a graph's pool must not outlive it on a module
         bn.__dict__["_pn2_eval_coeff"] = (key, scale, shift)
     return scale, shift
+
+
+def refresh_eval_coefficients(module):
+    """Recompute (in place) the cached eval coefficients of every BatchNorm below `module` from its current weights and
+    running statistics: what a replayed inference graph needs after the model was trained further."""
+    lib = _lib.load()
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) and "_pn2_eval_coeff" in m.__dict__ and m.weight is not None:
+            dev = m.weight.device
+            with torch.cuda.device(dev):
+                _eval_coefficients(lib, dev, m, m.weight, m.bias)
 
 
 class _MLPStack(torch.autograd.Function):
@@ -180,6 +210,8 @@ class _MLPStack(torch.autograd.Function):
                     out_args = (_ptr(z), Co if z is None else z.stride(0), _ptr(pm[0]), _ptr(pm[1]), _ptr(pm[2]), _ptr(pm[3]),
                                 rows_out, _ptr(y), _ptr(argk), _stream(dev))
                 if training:
+                    if l == 0:
+                        invalidate_eval_coefficients()     # running statistics are about to be rewritten by raw kernels
                     mean, invstd = torch.empty(Co, **f32), torch.empty(Co, **f32)
                     mom, mom_dev = momentum_word(bn, dev)
                     track = bn.track_running_stats and bn.running_mean is not None

@@ -116,15 +116,27 @@ class BallPlan:
     farthest_point_sample_plan() (tail of the FPS kernel) or ball_plan() (stand-alone kernel); valid for one
     (xyz, new_xyz, radius) triple."""
 
-    def __init__(self, buf, B, N, S, D, radius):
+    def __init__(self, buf, B, N, S, D, radius, xyz=None, new_xyz=None):
         self.buf, self.B, self.N, self.S, self.D, self.radius = buf, B, N, S, D, float(radius)
         self.rows_packed = False
+        # the tensors the plan was built from (held: their storage cannot be recycled under the plan) and, once rows are
+        # packed, the features they were packed from
+        self.xyz, self.new_xyz, self.points = xyz, new_xyz, None
 
-    def matches(self, B, N, S, D, radius):
-        return (self.B, self.N, self.S, self.D) == (B, N, S, D) and self.radius == float(radius)
+    @staticmethod
+    def _same(held, t):
+        return held is None or t is None or held is t or (held.data_ptr() == t.data_ptr() and held.shape == t.shape
+                                                          and held._version == t._version)
+
+    def matches(self, B, N, S, D, radius, xyz=None, new_xyz=None):
+        """True when the plan was built for this geometry: same sizes and radius, and (when the tensors are given) the
+        same xyz / new_xyz tensors -- a plan of another cloud of the same shape would silently return that cloud's
+        neighbours."""
+        return ((self.B, self.N, self.S, self.D) == (B, N, S, D) and self.radius == float(radius)
+                and self._same(self.xyz, xyz) and self._same(self.new_xyz, new_xyz))
 
     def pack_rows(self, xyz, points):
-        if self.rows_packed:
+        if self.rows_packed and self._same(self.points, points):
             return
         lib = _lib.load()
         dev = self.buf.device
@@ -132,6 +144,7 @@ class BallPlan:
             rc = lib.pn2_ball_pack_rows(_ptr(xyz), _ptr(points), self.B, self.N, self.S, self.D, _ptr(self.buf), _stream(dev))
         _lib.check(rc, "pn2_ball_pack_rows")
         self.rows_packed = True
+        self.points = points
 
 
 def plan_supported(B, N, S):
@@ -168,7 +181,7 @@ def farthest_point_sample_plan(xyz, npoint, radius, D, start=None):
                                                 int(D), _ptr(buf), _ptr(_err_word(dev)), _stream(dev))
     _lib.check(rc, "pn2_farthest_point_sample_plan")
     _after_fault_op(dev, "farthest_point_sample")
-    return idx, new_xyz, BallPlan(buf, B, N, npoint, D, radius)
+    return idx, new_xyz, BallPlan(buf, B, N, npoint, D, radius, xyz, new_xyz)
 
 
 def ball_plan(radius, xyz, new_xyz, points=None):
@@ -182,8 +195,9 @@ def ball_plan(radius, xyz, new_xyz, points=None):
     with torch.cuda.device(dev):
         rc = lib.pn2_ball_plan(float(radius), _ptr(xyz), _ptr(new_xyz), _ptr(points), B, N, S, D, _ptr(buf), _stream(dev))
     _lib.check(rc, "pn2_ball_plan")
-    plan = BallPlan(buf, B, N, S, D, radius)
+    plan = BallPlan(buf, B, N, S, D, radius, xyz, new_xyz)
     plan.rows_packed = True
+    plan.points = points
     return plan
 
 
@@ -214,7 +228,7 @@ def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, p
     ldg = _padded(3 + D, pad_to)
     idx = torch.empty((B, S, nsample), dtype=torch.int64, device=dev)
     grouped = torch.empty((B, S, nsample, ldg), dtype=torch.float32, device=dev) if want_grouped else None
-    if plan is not None and not (plan.matches(B, N, S, plan.D, radius) and (plan.D == D or not want_grouped)):
+    if plan is not None and not (plan.matches(B, N, S, plan.D, radius, xyz, new_xyz) and (plan.D == D or not want_grouped)):
         plan = None
     if plan is None and plan_supported(B, N, S) and nsample <= 64:
         plan = ball_plan(radius, xyz, new_xyz, points if want_grouped else None)

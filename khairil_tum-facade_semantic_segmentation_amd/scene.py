@@ -226,6 +226,148 @@ class DeviceBlockSampler:
         return out.cpu().numpy(), self.labels[sel].cpu().numpy()
 
 
+class DeviceSceneTiler:
+    """SceneTiler with the scene resident on the device (csrc/pn2_tiler.hip): the grid index is built
+    once on the host and uploaded, the window table (a few hundred rows) is enumerated on the host with the reference's
+    float64 arithmetic, and the points of every window are found, topped up, shuffled and laid out as blocks by two
+    kernel launches and one small device -> host copy (the window populations, which size the output).
+    tile(seed): randomness from keyed pseudo-random permutations of `seed` -- same seed, same tiling on every rank.
+    tile_exact(rng): replays numpy's choice() / shuffle() call sequence of the reference from the window populations and
+    yields the reference's blocks bit for bit (given the same global numpy RNG state).
+    Both return device tensors (data [nb, bp, 6+E] float32, labels [nb, bp] int64, weights [nb, bp] float32, point
+    indices [nb, bp] int64) that infer_scene() consumes without a host round trip."""
+
+    def __init__(self, points, labels, extra=(), feature_name=(), labelweights=None, block_points=4096, block_size=1.0,
+                 stride=0.5, padding=0.001, device="cuda"):
+        import torch
+        self.torch = torch
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64)[:, :3])
+        self.P = pts.shape[0]
+        self.block_points, self.block_size, self.stride, self.padding = int(block_points), float(block_size), float(stride), float(padding)
+        self.cmin, self.cmax = pts.min(axis=0), pts.max(axis=0)
+        gi = GridIndex(pts[:, :2], cell=block_size / 4.0)
+        self.grid = gi
+        dev = torch.device(device)
+        self.dev = dev
+        self.xyz = torch.from_numpy(pts).to(dev)
+        self.order = torch.from_numpy(gi.order.astype(np.int32)).to(dev)
+        self.cell_start = torch.from_numpy(gi.start.astype(np.int32)).to(dev)
+        lab = np.asarray(labels).astype(np.int64)
+        self.labels = torch.from_numpy(lab).to(dev)
+        lw = np.ones(int(lab.max()) + 1) if labelweights is None else np.asarray(labelweights, dtype=np.float64)
+        self.num_classes = int(lw.shape[0])
+        self.labelweights = torch.from_numpy(lw.astype(np.float32)).to(dev)
+        cols = []
+        for e, name in zip(extra, feature_name):
+            e = np.asarray(e, dtype=np.float64)
+            cols.append((e / 255 if name in ("red", "blue", "green") else e).astype(np.float32))      # :233-234
+        self.E = len(cols)
+        self.extra = torch.from_numpy(np.stack(cols)).to(dev) if cols else None
+        # the window grid of :187-201, in the reference's order (y outer, x inner) and arithmetic
+        bs, st, pad = self.block_size, self.stride, self.padding
+        gx = int(np.ceil(float(self.cmax[0] - self.cmin[0] - bs) / st) + 1)
+        gy = int(np.ceil(float(self.cmax[1] - self.cmin[1] - bs) / st) + 1)
+        win, centre = [], []
+        for iy in range(gy):
+            for ix in range(gx):
+                ex = min(self.cmin[0] + ix * st + bs, self.cmax[0])
+                sx = ex - bs
+                ey = min(self.cmin[1] + iy * st + bs, self.cmax[1])
+                sy = ey - bs
+                win.append((sx - pad, ex + pad, sy - pad, ey + pad))
+                centre.append((sx + bs / 2.0, sy + bs / 2.0))
+        self.windows = np.asarray(win, dtype=np.float64).reshape(-1, 4)
+        self.centres = np.asarray(centre, dtype=np.float64).reshape(-1, 2)
+        self._members = None                         # (window table, counts, offsets, member lists): geometry only, built once
+
+    def _lib(self):
+        from . import _lib
+        return _lib, _lib.load()
+
+    def _find_members(self, ascending=False):
+        """Window populations and member lists (independent of the seed).  ascending: every window's list in ascending point
+        index -- what np.where yields in the reference; only the exact replay needs it."""
+        torch = self.torch
+        if self._members is not None and (self._members["ascending"] or not ascending):
+            return self._members
+        L, lib = self._lib()
+        gi = self.grid
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        W = self.windows.shape[0]
+        win = torch.from_numpy(self.windows).to(self.dev)
+        counts = torch.empty(W, dtype=torch.int32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            rc = lib.pn2_tile_windows(self.xyz.data_ptr(), self.order.data_ptr(), self.cell_start.data_ptr(), float(gi.origin[0]),
+                                      float(gi.origin[1]), float(gi.cell), gi.nx, gi.ny, win.data_ptr(), W, None, counts.data_ptr(),
+                                      None, st)
+        L.check(rc, "pn2_tile_windows")
+        cnt = counts.cpu().numpy().astype(np.int64)             # the one host sync of a tiling: it sizes the output
+        keep = np.nonzero(cnt > 0)[0]                           # `if point_idxs.size == 0: continue` (:204)
+        cnt = cnt[keep]
+        win_k = torch.from_numpy(np.ascontiguousarray(self.windows[keep])).to(self.dev)
+        off = np.concatenate(([0], np.cumsum(cnt)))
+        nblk = (cnt + self.block_points - 1) // self.block_points
+        boff = np.concatenate(([0], np.cumsum(nblk)))
+        members = torch.empty(int(off[-1]), dtype=torch.int32, device=self.dev)
+        moff = torch.from_numpy(off[:-1].copy()).to(self.dev)
+        if keep.size:
+            with torch.cuda.device(self.dev):
+                rc = lib.pn2_tile_windows(self.xyz.data_ptr(), self.order.data_ptr(), self.cell_start.data_ptr(), float(gi.origin[0]),
+                                          float(gi.origin[1]), float(gi.cell), gi.nx, gi.ny, win_k.data_ptr(), int(keep.size),
+                                          moff.data_ptr(), None, members.data_ptr(), st)
+            L.check(rc, "pn2_tile_windows")
+        if ascending and keep.size:
+            wid = torch.repeat_interleave(torch.arange(keep.size, device=self.dev), torch.from_numpy(cnt).to(self.dev))
+            key = (wid.to(torch.int64) << 32) | members.to(torch.int64)
+            members = (torch.sort(key)[0] & 0xFFFFFFFF).to(torch.int32)
+        self._members = {"ascending": ascending, "keep": keep, "cnt": cnt, "off": off, "boff": boff, "members": members, "moff": moff,
+                         "counts": torch.from_numpy(cnt.astype(np.int32)).to(self.dev),
+                         "centre": torch.from_numpy(np.ascontiguousarray(self.centres[keep])).to(self.dev),
+                         "boff_dev": torch.from_numpy(boff).to(self.dev)}
+        return self._members
+
+    def _fill(self, m, srcpos, seed):
+        import ctypes
+        torch = self.torch
+        L, lib = self._lib()
+        nb, bp, F = int(m["boff"][-1]), self.block_points, 6 + self.E
+        data = torch.empty((nb, bp, F), dtype=torch.float32, device=self.dev)
+        labels = torch.empty((nb, bp), dtype=torch.int64, device=self.dev)
+        weight = torch.empty((nb, bp), dtype=torch.float32, device=self.dev)
+        index = torch.empty((nb, bp), dtype=torch.int64, device=self.dev)
+        cm = (ctypes.c_double * 3)(*[float(v) for v in self.cmax])
+        with torch.cuda.device(self.dev):
+            rc = lib.pn2_tile_fill(self.xyz.data_ptr(), None if self.extra is None else self.extra.data_ptr(), self.labels.data_ptr(),
+                                   self.labelweights.data_ptr(), self.P, self.E, self.num_classes, cm, m["members"].data_ptr(),
+                                   m["moff"].data_ptr(), m["counts"].data_ptr(), m["centre"].data_ptr(), m["boff_dev"].data_ptr(),
+                                   int(m["keep"].size), nb, bp, None if srcpos is None else srcpos.data_ptr(),
+                                   int(seed) & (2 ** 64 - 1), data.data_ptr(), labels.data_ptr(), weight.data_ptr(), index.data_ptr(),
+                                   torch.cuda.current_stream(self.dev).cuda_stream)
+        L.check(rc, "pn2_tile_fill")
+        return data, labels, weight, index
+
+    def tile(self, seed=0):
+        return self._fill(self._find_members(), None, seed)
+
+    def tile_exact(self, rng=np.random):
+        """The reference's own random stream: per non-empty window rng.choice(population, top-up, replace) then
+        rng.shuffle over the window's slots (:209-212) -- both consume the stream as a function of the sizes only, so the
+        host draws POSITIONS and the device gathers."""
+        m = self._find_members(ascending=True)
+        bp = self.block_points
+        parts = []
+        for c in m["cnt"]:
+            c = int(c)
+            size = int(np.ceil(c / bp)) * bp
+            fill = size - c
+            rep = rng.choice(c, fill, replace=False if fill <= c else True)
+            src = np.concatenate((np.arange(c), rep))
+            rng.shuffle(src)
+            parts.append(src)
+        srcpos = self.torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(self.dev) if parts else None
+        return self._fill(m, srcpos, 0)
+
+
 class VotePool:
     """vote_label_pool of modelTesting (localfunctions.py:373-403) kept on the device as int32
     [num_points, num_classes]; add() scatters one vote per (point, arg-max class) with the HIP
@@ -279,8 +421,11 @@ class BlockInferencer:
     through the MLP stacks, the FPS / ball-query / 3-NN pyramid of sub-batch i+1 (with the first level's grouped rows and
     the laid-out input) is computed on a parallel branch of the same graph and handed over with one copy -- the scheme of
     train.SemSegTrainer, forward only.  BatchNorm is frozen (eval), so blocks are independent: a short last sub-batch is
-    padded with copies of its last block.  The graph holds the model's eval coefficients as they were when it was
-    captured: build a new inferencer after changing the weights."""
+    padded with copies of its last block.  The graph reads the weights through the pointers they had at capture and the
+    eval-mode BatchNorm coefficients from the tensors cached on the modules: after further training call
+    mlp.refresh_eval_coefficients(model) (train.eval_epoch does) and the replays see the new values; if the parameters
+    were re-homed since (train.FlatAdam moves them into one flat buffer when a trainer is created), run() notices and
+    captures again."""
 
     def __init__(self, model, batch_size, channels, num_point):
         import torch
@@ -294,7 +439,11 @@ class BlockInferencer:
         self.next_x = torch.zeros_like(self.cur_x)
         self._side = torch.cuda.Stream(device=self.dev)
         self._graph = None
+        self._captured_ptrs = None
         self.logp = None
+
+    def _param_ptrs(self):
+        return [t.data_ptr() for t in list(self.model.parameters()) + list(self.model.buffers())]
 
     def _geometry_of(self, x):
         prepared = self.model.prepare_input(x, None)
@@ -327,6 +476,7 @@ class BlockInferencer:
                 self._cur.append(self._flat[off:off + nbytes].view(t.dtype).view(t.shape))
                 off += nbytes + (0 if padt is None else padt.numel())
             torch.cuda.synchronize(self.dev)
+            self._captured_ptrs = self._param_ptrs()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 main = torch.cuda.current_stream()
@@ -358,6 +508,8 @@ class BlockInferencer:
                 if b < self.B:
                     dst[b:].copy_(src[b - 1:b].expand(self.B - b, -1, -1))
                 return b
+            if self._graph is not None and self._captured_ptrs != self._param_ptrs():
+                self._graph = None                                # the parameters live elsewhere now: the graph reads stale memory
             if self._graph is None:
                 self._capture()
             load(self.next_x, batches[0])
@@ -370,8 +522,28 @@ class BlockInferencer:
                 consume(i, self.logp[:b])
 
 
+def scene_metrics(pred_label, labels, num_classes):
+    """Per-class seen / correct / union counters of one scene and what modelTesting logs from them
+    (localfunctions.py:409-421, 463-479): IoU = correct / (union + 1e-6) per class, `mIoU` their mean over ALL classes
+    (:477), `scene_mIoU` the mean over the classes that occur in the scene (:418-419), accuracies (:478-479).
+    pred_label / labels: tensors or arrays [P]."""
+    import torch
+    pred = torch.as_tensor(pred_label).reshape(-1).to(torch.int64)
+    lab = torch.as_tensor(labels).reshape(-1).to(torch.int64).to(pred.device)
+    C = int(num_classes)
+    seen = torch.bincount(lab, minlength=C)[:C]
+    hit = pred == lab
+    correct = torch.bincount(lab[hit], minlength=C)[:C]
+    union = seen + torch.bincount(pred, minlength=C)[:C] - correct           # |pred == l or label == l|
+    seen, correct, union = (t.cpu().numpy().astype(np.float64) for t in (seen, correct, union))
+    iou = correct / (union + 1e-6)
+    return {"class_seen": seen, "class_correct": correct, "class_union": union, "IoU": iou, "mIoU": float(iou.mean()),
+            "scene_mIoU": float(iou[seen != 0].mean()) if (seen != 0).any() else 0.0,
+            "avg_class_acc": float((correct / (seen + 1e-6)).mean()), "accuracy": float(correct.sum() / (seen.sum() + 1e-6))}
+
+
 def infer_scene(model, data_room, index_room, sample_weight, num_points, num_classes, batch_size=32, num_votes=1,
-                retile=None, group=None, graphs=False):
+                retile=None, group=None, graphs=False, return_votes=False):
     """Whole-scene voting inference (localfunctions.py:375-405): run the network over the scene's
     blocks in sub-batches, vote on the device, return the per-point predicted label tensor.
     `retile`, if given, is called before every vote round after the first to re-draw the blocks
@@ -410,4 +582,5 @@ def infer_scene(model, data_room, index_room, sample_weight, num_points, num_cla
                 logp, _ = model(x)
                 votes.add(logp=logp, point_idx=torch.as_tensor(index_room[s:s + batch_size], device=dev),
                           weight=torch.as_tensor(sample_weight[s:s + batch_size], dtype=torch.float32, device=dev))
-    return votes.all_reduce(group).labels()
+    votes.all_reduce(group)
+    return (votes.labels(), votes.pool) if return_votes else votes.labels()

@@ -140,6 +140,7 @@ class FlatAdam:
         if rc == self._lib.ERR_UNSUPPORTED:
             return False
         self._lib.check(rc, "pn2_adam_step_scattered")
+        mlp.invalidate_eval_coefficients()                 # gamma / beta changed through raw pointers
         return True
 
     def step(self, flat_grad, grad_scale=1.0):
@@ -151,6 +152,7 @@ class FlatAdam:
                                    self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
                                    torch.cuda.current_stream(dev).cuda_stream)
         self._lib.check(rc, "pn2_adam_step")
+        mlp.invalidate_eval_coefficients()
 
 
 class SemSegTrainer:
@@ -193,7 +195,7 @@ class SemSegTrainer:
         self._prepares = hasattr(model, "prepare_input")        # the pyramid hands the prepared input rows over too
         self._unit = torch.ones((), dtype=torch.float32, device=next(model.parameters()).device) if on_gpu else None
         self._geo_next = None            # pyramid computed for the coming step
-        self._geo_next_src = None        # identity (data_ptr, version, shape) of the batch it was computed from
+        self._geo_next_src = None        # the batch it was computed from: (the tensor itself, its version)
         self._captured_mode = None       # (exchange, world) the graphs were captured for
         self._geo_event = None
         self._geo_cur = None             # (graph mode) static buffers the forward reads
@@ -255,7 +257,23 @@ class SemSegTrainer:
 
     @staticmethod
     def _identity(t):
-        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+        """What "the batch the pyramid was computed from" means: THE tensor object (held, so that the allocator cannot hand
+        its address to another batch while the pyramid is pending -- sampler and .to() outputs are written by raw kernels
+        and all carry version 0) at the version it had."""
+        return None if t is None else (t, t._version)
+
+    @staticmethod
+    def _same_batch(src, t):
+        if src is None or t is None or src[1] != t._version:
+            return False
+        held = src[0]                    # alive, so its storage is: a tensor with the same address aliases the same memory
+        return held is t or (held.data_ptr() == t.data_ptr() and held.shape == t.shape and held.stride() == t.stride()
+                             and held.dtype == t.dtype)
+
+    def drop_prefetched(self):
+        """Forget the pyramid computed for an announced batch that will not come (end of an epoch)."""
+        self._geo_next = None
+        self._geo_next_src = None
 
     def _exchange(self):
         """True when gradients go through the packed-buffer all-reduce.  PN2_FORCE_DP_PATH=1 takes
@@ -323,7 +341,7 @@ class SemSegTrainer:
             main = torch.cuda.current_stream()
             # the prefetched pyramid belongs to the tensor it was computed from: any other batch (or the same tensor
             # modified in place since) gets its own pyramid now instead of silently grouping with foreign indices
-            if self._geo_next is None or self._geo_next_src != self._identity(blocks_cf):
+            if self._geo_next is None or not self._same_batch(self._geo_next_src, blocks_cf):
                 self._geo_next = self._launch_prefetch(blocks_cf)
             main.wait_stream(self._side)
             geo, self._geo_next = self._geo_next, None
@@ -405,6 +423,7 @@ class SemSegTrainer:
         NEXT call will train on (default: the same batch again).  Returns the (rank-local) loss
         tensor, no host sync."""
         self.model.train()
+        mlp.invalidate_eval_coefficients()                 # a replayed graph rewrites weights and running statistics
         if not self.graphs:
             return self._eager_step(blocks_cf, target, next_blocks_cf)
         if self._g_fwd_bwd is None:
@@ -424,7 +443,7 @@ class SemSegTrainer:
         if target.data_ptr() != self._static_y.data_ptr():
             self._static_y.copy_(target)
         if self.prefetch:
-            if self._geo_next_src != self._identity(blocks_cf):
+            if not self._same_batch(self._geo_next_src, blocks_cf):
                 # the pyramid in `cur` was computed for another batch (the caller did not announce this one as
                 # next_blocks_cf): compute this batch's pyramid now, on the main stream, before the replay reads it
                 self._geo_flat.copy_(self._pack_geometry(self._geometry_of(self._static_x)))
@@ -446,31 +465,149 @@ def epoch_schedule(epoch, learning_rate=1e-3, lr_decay=0.7, step_size=10):
     return lr, momentum
 
 
-def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_rate=1e-3, lr_decay=0.7, step_size=10):
+def _mix(*words):
+    """64-bit counter hash (splitmix64 finaliser over the words): the seeds of the loops below."""
+    x = 0x9E3779B97F4A7C15
+    for w in words:
+        x = (x ^ (int(w) & 0xFFFFFFFFFFFFFFFF)) * 0xBF58476D1CE4E5B9 & 0xFFFFFFFFFFFFFFFF
+        x = (x ^ (x >> 31)) * 0x94D049BB133111EB & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 29
+    return x
+
+
+def batch_plan(room_sizes, batch_size, seed, epoch, step, rank=0):
+    """Which room every block of a batch comes from, and the sampler seed per room -- a pure function of
+    (seed, epoch, step, rank).  The reference replicates each room's index in proportion to its point count and shuffles
+    the list (room_idxs, sem_seg_training.py:184-193; DataLoader shuffle=True): a block's room is drawn with probability
+    num_points_room / total, and a batch mixes rooms.  The rank enters the hash, so the replicas of a data-parallel job
+    draw DIFFERENT blocks (rank r takes its own share of every global batch).
+    -> (counts per room [R], seeds per room [R])."""
+    import numpy as np
+    sizes = np.asarray(room_sizes, dtype=np.float64)
+    rs = np.random.RandomState(_mix(seed, epoch, step, rank) & 0xFFFFFFFF)
+    rooms = rs.choice(len(sizes), size=batch_size, p=sizes / sizes.sum())
+    counts = np.bincount(rooms, minlength=len(sizes))
+    seeds = [_mix(seed, epoch, step, rank, r + 1) for r in range(len(sizes))]
+    return counts, seeds
+
+
+def draw_batch(samplers, batch_size, seed, epoch, step, rank=0):
+    """One training batch from the device samplers (one scene.DeviceBlockSampler per room) by batch_plan().
+    -> (blocks [B,C,N] channel-first view like the loop's points.transpose(2, 1), labels [B,N])"""
+    counts, seeds = batch_plan([sp.P for sp in samplers], batch_size, seed, epoch, step, rank)
+    feats, labels = [], []
+    for sp, n, sd in zip(samplers, counts, seeds):
+        if n:
+            f, l, _ = sp.sample(int(n), seed=sd)
+            feats.append(f)
+            labels.append(l)
+    f = feats[0] if len(feats) == 1 else torch.cat(feats)
+    l = labels[0] if len(labels) == 1 else torch.cat(labels)
+    return f.permute(0, 2, 1), l
+
+
+def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_rate=1e-3, lr_decay=0.7, step_size=10, rank=None):
     """One epoch of the reference's training loop (modelTraining, localfunctions.py:184-227) with every per-step piece
-    on the device: blocks drawn by scene.DeviceBlockSampler (one per room; a batch comes from one room, rooms
-    taken in turn), rotate-z inside the input kernel and accuracy counters on the device (construct the trainer with
-    augment=True, metrics=True), the epoch's learning rate and BatchNorm momentum applied graph-safely.  The next
-    batch is drawn before the current one is stepped, so the trainer's geometry prefetch runs on it meanwhile.
-    -> {"loss": mean loss, "accuracy": ..., "lr": ..., "bn_momentum": ...} (one host sync at the end)."""
+    on the device: blocks drawn by scene.DeviceBlockSampler (one per room; every block's room drawn in proportion to the
+    rooms' point counts, batch_plan()), rotate-z inside the input kernel and accuracy counters on the device (construct
+    the trainer with augment=True, metrics=True), the epoch's learning rate and BatchNorm momentum applied graph-safely.
+    The next batch is drawn before the current one is stepped, so the trainer's geometry prefetch runs on it meanwhile.
+    rank (default: this process's rank in the trainer's group) enters the sampling seed: replicas train on different
+    blocks.  -> {"loss": mean loss, "accuracy": ..., "lr": ..., "bn_momentum": ...} (one host sync at the end)."""
     lr, momentum = epoch_schedule(epoch, learning_rate, lr_decay, step_size)
     trainer.set_lr(lr)
     trainer.set_bn_momentum(momentum)
     if trainer.metrics is not None:
         trainer.metrics.reset()
+    if rank is None:
+        rank = dist.get_rank(trainer.group) if (dist.is_available() and dist.is_initialized()) else 0
 
-    def draw(i):
-        sp = samplers[i % len(samplers)]
-        feats, labels, _ = sp.sample(batch_size, seed=(seed * 1000003 + epoch) * 1000003 + i)
-        return feats.permute(0, 2, 1), labels                  # channel-first view, like the loop's points.transpose(2, 1)
-
-    nxt = draw(0)
+    nxt = draw_batch(samplers, batch_size, seed, epoch, 0, rank)
     loss_sum = None
     for i in range(steps):
-        cur, nxt = nxt, draw(i + 1) if i + 1 < steps else None
+        cur, nxt = nxt, draw_batch(samplers, batch_size, seed, epoch, i + 1, rank) if i + 1 < steps else None
         loss = trainer.step(cur[0], cur[1], None if nxt is None else nxt[0])
         loss_sum = loss.clone() if loss_sum is None else loss_sum + loss
+    trainer.drop_prefetched()                              # the last batch was announced as its own successor
     out = {"loss": float(loss_sum) / max(steps, 1), "lr": lr, "bn_momentum": momentum}
     if trainer.metrics is not None:
         out.update(trainer.metrics.read())
+    return out
+
+
+def label_weights(labels_per_room, num_classes, device=None):
+    """calculate_labelweights of the reference's datasets (sem_seg_training.py:264-278): histogram of the labels of all
+    rooms, normalised, then (max / w) ** (1/3) -- the class weights the loops pass to nll_loss.  The histogram runs on
+    the device the labels live on (torch.bincount); a class that never occurs gets inf, like the reference's division.
+    -> float32 tensor [num_classes]"""
+    total = None
+    for lab in labels_per_room:
+        lab = torch.as_tensor(lab)
+        if device is not None:
+            lab = lab.to(device)
+        h = torch.bincount(lab.reshape(-1).to(torch.int64), minlength=num_classes)[:num_classes]
+        total = h if total is None else total + h
+    w = total.to(torch.float32)
+    w = w / w.sum()
+    return torch.pow(w.max() / w, 1.0 / 3.0)
+
+
+class BestModel:
+    """The reference's checkpoint rule (localfunctions.py:310-322): keep the state whenever the evaluation mIoU is at
+    least the best so far."""
+
+    def __init__(self):
+        self.best_iou = 0.0
+        self.epoch = None
+        self.state = None
+
+    def update(self, epoch, miou, model):
+        if miou >= self.best_iou:
+            self.best_iou, self.epoch = float(miou), epoch
+            self.state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            return True
+        return False
+
+
+def eval_epoch(model, batches, class_weight=None, batch_size=None, engine=None, metrics=None):
+    """The per-epoch evaluation of the reference loop (localfunctions.py:243-308): eval mode, no gradients, over
+    `batches` (an iterable of (blocks [b,C,N] channel-first, target [b,N])): mean nll_loss(weight) over the batches,
+    accuracy, per-class seen / correct / union counters, mIoU = mean(correct / (union + 1e-6)) (:283), average class
+    accuracy (:287-288).  The counters stay on the device (ops.SegMetrics, one kernel per batch) and are read once.
+    engine = a scene.BlockInferencer of the model (fixed sub-batch shape): the forward passes are replays of ONE captured
+    graph with the next sub-batch's geometry prefetched; its eval coefficients are refreshed from the current weights
+    first (mlp.refresh_eval_coefficients).  -> dict like SegMetrics.read() plus "loss"."""
+    from .ops import SegMetrics
+    from .models.pointnet2_sem_seg import get_loss
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device
+    crit = get_loss()
+    batches = list(batches)
+    if not batches:
+        raise ValueError("eval_epoch: no batches")
+    ncls = model.conv2.out_channels
+    m = metrics if metrics is not None else SegMetrics(ncls, dev)
+    m.reset()
+    loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        if engine is not None:
+            mlp.refresh_eval_coefficients(model)
+
+            def consume(i, logp):
+                tgt = batches[i][1].to(dev)
+                nonlocal loss_sum
+                loss_sum = loss_sum + crit(logp.reshape(-1, ncls), tgt.reshape(-1), None, class_weight)
+                m.add(logp, tgt)
+            engine.run([b[0] for b in batches], consume)
+        else:
+            for x, tgt in batches:
+                x, tgt = x.to(dev), tgt.to(dev)
+                logp, _ = model(x)
+                loss_sum = loss_sum + crit(logp.reshape(-1, ncls), tgt.reshape(-1), None, class_weight)
+                m.add(logp, tgt)
+    out = m.read()
+    out["loss"] = float(loss_sum) / len(batches)            # loss_sum / num_batches (:285)
+    if was_training:
+        model.train()
     return out

@@ -38,22 +38,24 @@ def test_planned_query_matches_golden_both_producers(pn2, orc, synth, golden, ki
     blocks, _, _, _ = synth.draw_case(int(g["seed"]), 2, 4096, 9, kind)
     xyz = np.ascontiguousarray(blocks[:, :, :3])
     want_idx = g["ball1"].astype(np.int64)
-    # producer 1: the tail of the FPS kernel
-    fps, new_xyz, plan = pn2.ops.farthest_point_sample_plan(dev(pn2, xyz), 1024, 0.1, 9, dev(pn2, g["start1"]))
+    # producer 1: the tail of the FPS kernel (a plan belongs to the tensors it was built from: the same device tensors
+    # go to the query)
+    dxyz = dev(pn2, xyz)
+    fps, new_xyz, plan = pn2.ops.farthest_point_sample_plan(dxyz, 1024, 0.1, 9, dev(pn2, g["start1"]))
     assert np.array_equal(host(fps), g["fps1"].astype(np.int64))
     want_xyz = orc.index_points(xyz, host(fps))
     assert np.array_equal(host(new_xyz), want_xyz)
-    idx, grouped = pn2.ops.ball_query_group(0.1, 32, dev(pn2, xyz), new_xyz, dev(pn2, blocks), plan=plan)
+    idx, grouped = pn2.ops.ball_query_group(0.1, 32, dxyz, new_xyz, dev(pn2, blocks), plan=plan)
     assert plan.rows_packed
     assert np.array_equal(host(idx), want_idx)
     assert np.array_equal(host(grouped), orc.group_points(xyz, want_xyz, blocks, want_idx))
     assert np.array_equal(host(grouped)[:, ::41], g["group1_rows"])
     # producer 2: the stand-alone kernels, indices only
-    plan2 = pn2.ops.ball_plan(0.1, dev(pn2, xyz), new_xyz, None)
-    assert np.array_equal(host(pn2.ops.query_ball_point(0.1, 32, dev(pn2, xyz), new_xyz, plan=plan2)), want_idx)
+    plan2 = pn2.ops.ball_plan(0.1, dxyz, new_xyz, None)
+    assert np.array_equal(host(pn2.ops.query_ball_point(0.1, 32, dxyz, new_xyz, plan=plan2)), want_idx)
     # a plan for another radius is not used
-    other = pn2.ops.ball_plan(0.2, dev(pn2, xyz), new_xyz, None)
-    assert np.array_equal(host(pn2.ops.query_ball_point(0.1, 32, dev(pn2, xyz), new_xyz, plan=other)), want_idx)
+    other = pn2.ops.ball_plan(0.2, dxyz, new_xyz, None)
+    assert np.array_equal(host(pn2.ops.query_ball_point(0.1, 32, dxyz, new_xyz, plan=other)), want_idx)
     pn2.ops.check_errors()
 
 
@@ -73,20 +75,22 @@ def test_planned_query_shapes(pn2, orc, shape):
     xyz = rs.uniform(0.0, 1.0, size=(B, N, 3)).astype(np.float32)
     pts = rs.normal(size=(B, N, D)).astype(np.float32)
     start = rs.randint(0, N, size=(B,))
-    fps, new_xyz, plan = pn2.ops.farthest_point_sample_plan(dev(pn2, xyz), S, radius, D, dev(pn2, start))
+    dxyz, dpts = dev(pn2, xyz), dev(pn2, pts)
+    fps, new_xyz, plan = pn2.ops.farthest_point_sample_plan(dxyz, S, radius, D, dev(pn2, start))
     want_fps = orc.farthest_point_sample(xyz, S, start)
     assert np.array_equal(host(fps), want_fps)
     cxyz = orc.index_points(xyz, want_fps)
     want = orc.query_ball_point(radius, K, xyz, cxyz)
-    idx, grouped = pn2.ops.ball_query_group(radius, K, dev(pn2, xyz), new_xyz, dev(pn2, pts), pad_to=pad_to, plan=plan)
+    idx, grouped = pn2.ops.ball_query_group(radius, K, dxyz, new_xyz, dpts, pad_to=pad_to, plan=plan)
+    assert plan.xyz is dxyz or plan.xyz.data_ptr() == dxyz.data_ptr()
     assert np.array_equal(host(idx), want)
     ref = orc.group_points(xyz, cxyz, pts, want)
     got = host(grouped)
     assert np.array_equal(got[..., :3 + D], ref)
     assert not got[..., 3 + D:].any()
     # stand-alone producer, same answer
-    idx2, grouped2 = pn2.ops.ball_query_group(radius, K, dev(pn2, xyz), new_xyz, dev(pn2, pts), pad_to=pad_to,
-                                              plan=pn2.ops.ball_plan(radius, dev(pn2, xyz), new_xyz, dev(pn2, pts)))
+    idx2, grouped2 = pn2.ops.ball_query_group(radius, K, dxyz, new_xyz, dpts, pad_to=pad_to,
+                                              plan=pn2.ops.ball_plan(radius, dxyz, new_xyz, dpts))
     assert np.array_equal(host(idx2), want)
     assert np.array_equal(host(grouped2), got)
     pn2.ops.check_errors()
@@ -103,8 +107,9 @@ def test_planned_query_foreign_centroids_and_empty_balls(pn2, orc):
     new_xyz[:, :8] = np.array([2.0, 2.0, 2.0], np.float32)          # far outside: empty
     want = orc.query_ball_point(0.1, K, xyz, new_xyz, allow_empty=True)
     assert (want == N).any() and (want < N).any()
-    plan = pn2.ops.ball_plan(0.1, dev(pn2, xyz), dev(pn2, new_xyz), dev(pn2, pts))
-    idx, grouped = pn2.ops.ball_query_group(0.1, K, dev(pn2, xyz), dev(pn2, new_xyz), dev(pn2, pts), plan=plan)
+    dxyz, dnew, dpts = dev(pn2, xyz), dev(pn2, new_xyz), dev(pn2, pts)
+    plan = pn2.ops.ball_plan(0.1, dxyz, dnew, dpts)
+    idx, grouped = pn2.ops.ball_query_group(0.1, K, dxyz, dnew, dpts, plan=plan)
     assert np.array_equal(host(idx), want)
     got = host(grouped)
     empty = (want == N).all(-1)

@@ -111,9 +111,10 @@ def test_ball_query_group_ragged_shapes(pn2, orc, B, N, S, K, D):
                                               (70, 777, 65, 64, 1, 0.12), (33, 4000, 127, 32, 0, 0.12),
                                               (5, 3333, 1000, 7, 13, 0.12), (64, 64, 64, 32, 9, 0.12),
                                               (7, 4096, 640, 32, 9, 0.5), (9, 2500, 500, 8, 1, 2.0)])
-def test_ball_query_matrix_core_path_ragged(pn2, orc, B, N, S, K, D, radius):
-    """B*S >= 4096 and N <= 4096 take the MFMA kernel (pn2_ball_mfma.hip): ragged S / N / K, dense balls
-    (sub-list overflow + truncation), duplicates, with and without grouping."""
+def test_ball_query_many_centroids_ragged(pn2, orc, B, N, S, K, D, radius):
+    """B*S >= 4096 through ops (which plans blocks of more than 1024 points and otherwise takes the library's
+    self-contained choice: cell-pruned kernel for N >= 2048, vector-unit scan below): ragged S / N / K, dense balls
+    (truncation), duplicates, with and without grouping.  tests/test_hip_ball_kernels.py forces every kernel by name."""
     rs = np.random.RandomState(B + N + S)
     xyz = rs.uniform(-0.5, 0.5, size=(B, N, 3)).astype(np.float32)
     xyz[:, :, 1] *= 0.05                                     # thin slab: many balls exceed K (and K+32) hits
@@ -134,7 +135,7 @@ def test_ball_query_matrix_core_path_ragged(pn2, orc, B, N, S, K, D, radius):
     pn2.ops.check_errors()
 
 
-def test_ball_query_matrix_core_path_empty_balls(pn2):
+def test_ball_query_empty_balls_report_an_error(pn2):
     xyz = np.zeros((8, 512, 3), np.float32)
     far = np.full((8, 512, 3), 3.0, np.float32)
     far[:, ::2] = 0.0                                        # every other centroid sits on the points
@@ -423,8 +424,9 @@ def test_full_size_properties_b16(pn2, orc, synth):
 
 @pytest.mark.parametrize("case", ["offset", "huge_coords", "nan_block", "outside", "clustered", "degenerate_axis"])
 def test_ball_query_cell_pruned_path(pn2, orc, case):
-    """B*S >= 4096 and N >= 2048 take the cell-pruned kernel (pn2_ball_grid.hip).  Its candidate set must
-    never change the result: coordinates far from the origin (rounding of the reference's distance
+    """B*S >= 4096 and 1024 < N <= 8192: ops builds a plan and runs the binned query (pn2_ball_binned.hip); the same
+    cases go through the cell-pruned kernel (pn2_ball_grid.hip) by name in tests/test_hip_ball_kernels.py.  A candidate
+    set must never change the result: coordinates far from the origin (rounding of the reference's distance
     expression grows with |p|^2), non-finite coordinates, centroids outside the cloud's bounding box,
     dense clusters (hit-list overflow -> ordered rescan) and clouds flat in one axis."""
     rs = np.random.RandomState(len(case))
