@@ -38,10 +38,22 @@ def ball_group_algorithmic_bytes(B, N, S, K, D):
     return B * (N * 3 * 4 + S * 3 * 4 + N * D * 4 + S * K * 8 + S * K * (3 + D) * 4)
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """The CPU oracle (oracle/: C index ops + torch CPU network), fwd+bwd+Adam on the same
-    synthetic blocks.  Bounded: at most 3 steps of B=16, stops once `seconds_budget` is spent; plus the legs
-    SURVEY.md 8(d) lists: one B=1 step (BASELINE configs[0]) and query_ball_point+group / FPS alone."""
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds_budget=14.0):
+    """The CPU oracle (oracle/: C index ops + torch CPU network), fwd+bwd+Adam on the same synthetic blocks, timed as
+    SURVEY.md 8(d) asks: one warm-up, then the MEDIAN of the timed repetitions -- at least 3 full B=16 steps (more while
+    the budget lasts, at most 5), 5 B=1 steps (BASELINE configs[0]), 7 runs each of FPS alone and of
+    query_ball_point + group alone; thread count and CPU model stated."""
     from khairil_tum_facade_semantic_segmentation_amd import synth
     from oracle import pn2_oracle as orc
     orc.build()
@@ -53,40 +65,56 @@ def cpu_baseline(seconds_budget=12.0):
     blocks, labels, starts, _ = synth.draw_case(synth.BENCH_SEED, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, "cube",
                                                 NUM_CLASSES)
     cf = np.ascontiguousarray(blocks.transpose(0, 2, 1))
-    net.train_step(cf[:2], labels[:2], [s[:2] for s in starts], opt)          # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 and (n == 0 or time.perf_counter() - t0 < seconds_budget):
-        net.train_step(cf, labels, starts, opt)
-        n += 1
-    dt = time.perf_counter() - t0
-    out = {"value": n * PER_GPU_BATCH * BLOCK_POINTS / dt, "unit": "points/s", "cores": threads, "kind": "port",
-           "sample": "%d fwd+bwd+Adam step(s) of %dx%dx%d cube blocks, %.1f s, oracle (C index ops + torch CPU)"
-                     % (n, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt)}
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    net.train_step(cf, labels, starts, opt)                                    # warm-up at the timed size
+    t_start = time.perf_counter()
+    steps = []
+    while len(steps) < 3 or (len(steps) < 5 and time.perf_counter() - t_start < seconds_budget):
+        steps.append(timed(lambda: net.train_step(cf, labels, starts, opt)))
+    dt = float(np.median(steps))
+    out = {"value": PER_GPU_BATCH * BLOCK_POINTS / dt, "unit": "points/s", "cores": threads, "kind": "port",
+           "cpu_model": host_cpu_model(),
+           "sample": "median of %d fwd+bwd+Adam steps of %dx%dx%d cube blocks after 1 warm-up (%.2f s each, min %.2f max %.2f), "
+                     "oracle (C index ops + torch CPU)" % (len(steps), PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt, min(steps), max(steps)),
+           "step_seconds": steps}
     # configs[0]: one 4096x9 block, one fwd+bwd(+Adam) step
-    t0 = time.perf_counter()
-    net.train_step(cf[:1], labels[:1], [s[:1] for s in starts], opt)
-    out["b1_step_points_per_s"] = BLOCK_POINTS / (time.perf_counter() - t0)
+    one = [s[:1] for s in starts]
+    net.train_step(cf[:1], labels[:1], one, opt)
+    b1 = [timed(lambda: net.train_step(cf[:1], labels[:1], one, opt)) for _ in range(5)]
+    out["b1_step_points_per_s"] = BLOCK_POINTS / float(np.median(b1))
     # the hot path alone, B = 16: FPS 4096 -> 1024, then query_ball_point + grouping (r = 0.1, K = 32, D = 9)
     xyz = np.ascontiguousarray(blocks[:, :, :3])
-    t0 = time.perf_counter()
-    fps = orc.farthest_point_sample(xyz, 1024, starts[0])
-    t_fps = time.perf_counter() - t0
+    fps = orc.farthest_point_sample(xyz, 1024, starts[0])                      # warm-up (threads, page faults)
+    t_fps = [timed(lambda: orc.farthest_point_sample(xyz, 1024, starts[0])) for _ in range(7)]
     cxyz = orc.index_points(xyz, fps)
-    t0 = time.perf_counter()
-    idx = orc.query_ball_point(0.1, 32, xyz, cxyz)
-    orc.group_points(xyz, cxyz, blocks, idx)
-    t_ball = time.perf_counter() - t0
-    out["fps_input_points_per_s"] = PER_GPU_BATCH * BLOCK_POINTS / t_fps
-    out["ball_query_group_input_points_per_s"] = PER_GPU_BATCH * BLOCK_POINTS / t_ball
+
+    def ball():
+        idx = orc.query_ball_point(0.1, 32, xyz, cxyz)
+        orc.group_points(xyz, cxyz, blocks, idx)
+    ball()
+    t_ball = [timed(ball) for _ in range(7)]
+    out["fps_input_points_per_s"] = PER_GPU_BATCH * BLOCK_POINTS / float(np.median(t_fps))
+    out["ball_query_group_input_points_per_s"] = PER_GPU_BATCH * BLOCK_POINTS / float(np.median(t_ball))
+    out["fps_seconds_min_median_max"] = [min(t_fps), float(np.median(t_fps)), max(t_fps)]
+    out["ball_seconds_min_median_max"] = [min(t_ball), float(np.median(t_ball)), max(t_ball)]
     return out
+
+
+def active_switches():
+    """PN2_* environment switches in effect (A/B and lab switches change what a line measures: they travel with it)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PN2_") and k != "PN2_BENCH_DRY_LAUNCH"}
 
 
 def kernel_source_hash():
     """sha256 over the sources of the kernel the roofline prices: a PMC traffic figure is only quoted while it
     was measured on exactly these sources."""
     h = hashlib.sha256()
-    for name in ("pn2_ball_binned.hip", "pn2_ball_bin.h", "pn2_common.h"):
+    for name in ("pn2_ball_grid.hip", "pn2_ball_binned.hip", "pn2_ball_bin.h", "pn2_common.h"):
         with open(os.path.join(REPO, "khairil_tum-facade_semantic_segmentation_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -142,6 +170,49 @@ def run_control(args, dev):
                          "activation_gbs": act_bytes / dt / 1e9, "activation_frac_of_hbm": act_bytes / dt / 1e9 / HBM_PEAK_GBS}}
 
 
+def run_drop_in(args, dev):
+    """BASELINE configs[1] through the reference's unchanged wiring on the drop-in operator surface (one GPU)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from dropin_wiring import build, loss_fn
+    from khairil_tum_facade_semantic_segmentation_amd import ops, synth
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_utils as U
+    blocks, labels, _, _ = synth.draw_case(synth.BENCH_SEED, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind, NUM_CLASSES)
+    x = torch.from_numpy(np.ascontiguousarray(blocks.transpose(0, 2, 1))).to(dev)
+    y = torch.from_numpy(labels).to(dev).view(-1)
+    model = build(U, NUM_CLASSES, CHANNELS - 6)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model = model.to(dev).train()
+    cw = torch.ones(NUM_CLASSES, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+
+    def step():
+        opt.zero_grad()
+        pred, _ = model(x)
+        loss = loss_fn(pred.contiguous().view(-1, NUM_CLASSES), y, cw)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    ops.check_errors()
+    assert torch.isfinite(loss).item()
+    pts = PER_GPU_BATCH * BLOCK_POINTS * args.steps
+    return {"metric": "points/sec fwd+bwd, 4096-pt blocks, pointnet2_sem_seg (drop-in mode: the reference's wiring on the HIP pointnet2_utils)",
+            "value": pts / dt, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "switches": active_switches(),
+            "config": {"workload": "pointnet2_sem_seg fwd+bwd+Adam through tests/dropin_wiring.py (channel-first module calls, torch head / "
+                                   "nll_loss / Adam, eager), batch=16x4096x%d synthetic %s blocks (BASELINE configs[1])" % (CHANNELS, args.kind),
+                       "global_batch": PER_GPU_BATCH, "points_per_block": BLOCK_POINTS, "parallelism": "dp1"}}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run as
     fresh child processes -- this parent has not touched the GPU -- and pass their output and exit code through."""
@@ -167,6 +238,10 @@ def main():
                     help="BASELINE configs[3]: the geometry-only 4096x6 blocks of the reference's --RGB_OFF (steps only; the roofline leg keeps the north_star shape D = 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--drop-in", action="store_true",
+                    help="time the DROP-IN mode: the reference's own wiring (tests/dropin_wiring.py: channel-first module calls, torch "
+                         "head, F.nll_loss, torch.optim.Adam, eager launches) on the package's models.pointnet2_utils -- what a maintainer "
+                         "gets who swaps only pointnet2_utils.py; none of the package's own fast-path wiring")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute each batch's FPS/ball-query/3-NN pyramid inside its own step instead of one step ahead on a side stream")
     args = ap.parse_args()
@@ -199,6 +274,13 @@ def main():
     if args.model == "pointnet_sem_seg":
         if rank == 0:
             print(json.dumps(run_control(args, dev)), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    if args.drop_in:
+        if rank == 0:
+            print(json.dumps(run_drop_in(args, dev)), flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -238,14 +320,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(loss).item(), "training step produced a non-finite loss"
+    # evidence that the collective ran over N ranks: backend, world size and the measured all-reduce of the packed gradient
+    dp_info = None
+    if use_dist:
+        flat = torch.zeros(trainer.grads.numel, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(dev)
+        ta = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(dev)
+        ar_us = (time.perf_counter() - ta) / 20 * 1e6
+        t = torch.tensor([ar_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dp_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gradient_bytes": trainer.grads.numel * 4,
+                   "all_reduce_us": float(t.item()), "collectives_per_step": 1}
 
-    # roofline of the north_star kernel: SA1 query_ball_point+group at B=16, N=4096, S=1024, K=32, D=9, same
-    # resident inputs as the timed steps.  The product path (models.pointnet2_utils.sample_and_group) is
-    # FPS-with-plan -> pack rows -> pn2_ball_query_group_planned; `kernel_ms` is the average duration of
-    # pn2_ball_query_group_planned's launch (it issues one kernel) over `reps` launches running back to back in a
-    # captured graph, between HIP events on the launch stream.  What building the plan costs is reported beside it
-    # (the producer launches: binning + row packing; and what the binning launch adds to an FPS call), and so is the
-    # self-contained entry pn2_ball_query_group, which needs no workspace and keeps its own kernel.
+    # roofline of the north_star kernel: SA1 query_ball_point+group at B=16, N=4096, S=1024, K=32, D=9, same resident
+    # inputs as the timed steps, priced at OPERATOR level: from (xyz, new_xyz, feats) to (idx, grouped), everything a
+    # caller with nothing prepared must launch = ONE call of pn2_ball_query_group (one launch of the cell-pruned
+    # kernel; what ops.ball_query_group / models.pointnet2_utils.sample_and_group run).  `kernel_ms` = its average
+    # duration over `reps` calls running back to back in a captured graph, between HIP events on the launch stream.
+    # Beside it: the planned pair (pn2_ball_plan + pn2_ball_query_group_planned) whose query launch alone is the
+    # fastest kernel of the library but whose plan a single-use caller pays in full, on both synthetic distributions.
     rblocks, _, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, args.kind, NUM_CLASSES)
     pts = torch.from_numpy(rblocks).to(dev)
     xyz = pts[:, :, :3].contiguous()
@@ -313,39 +411,42 @@ def main():
         return float(np.median(times))
 
     reps = 50
-    k_ms = back_to_back_ms(planned, reps)
-    # the same launch on the other synthetic distribution (dense facade slab: most balls truncated at nsample; sparse
-    # cube: most balls scanned to the end), beside the figure for the distribution the steps were timed on
+    algo = ball_group_algorithmic_bytes(PER_GPU_BATCH, BLOCK_POINTS, 1024, 32, CHANNELS)
+
+    def measure():
+        """-> operator ms (pn2_ball_query_group), planned query ms, plan ms (stand-alone producers)"""
+        return back_to_back_ms(selfcontained, reps), back_to_back_ms(planned, reps), back_to_back_ms(producers, reps)
+
+    op_ms, k_ms, prod_ms = measure()
+    # one event pair per call: includes the launch latency of an idle queue
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        selfcontained()
+        b.record()
+    torch.cuda.synchronize(dev)
+    op_ms_single = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    fps_plain_ms = back_to_back_ms(lambda: fps(False), 10)
+    # the same on the other synthetic distribution (dense facade slab: most balls truncated at nsample; sparse cube: most
+    # balls scanned to the end), beside the figures for the distribution the steps were timed on
     other_kind = "facade" if args.kind == "cube" else "cube"
     oblocks, _, _, _ = synth.draw_case(synth.BENCH_SEED + rank, PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, other_kind, NUM_CLASSES)
-    keep = (pts, xyz, new_xyz, plan)
     pts = torch.from_numpy(oblocks).to(dev)
     xyz = pts[:, :, :3].contiguous()
     _, new_xyz, plan = ops.farthest_point_sample_plan(xyz, 1024, 0.1, CHANNELS, start)
     plan.pack_rows(xyz, pts)
-    k_ms_other = back_to_back_ms(planned, reps)
-    pts, xyz, new_xyz, plan = keep
-    # one event pair per launch: includes the launch latency of an idle queue
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in ev:
-        a.record()
-        planned()
-        b.record()
-    torch.cuda.synchronize(dev)
-    k_ms_single = float(np.median([a.elapsed_time(b) for a, b in ev]))
-    self_ms = back_to_back_ms(selfcontained, reps)
-    prod_ms = back_to_back_ms(producers, reps)
-    fps_plain_ms = back_to_back_ms(lambda: fps(False), 10)
-    fps_plan_ms = back_to_back_ms(lambda: fps(True), 10)
+    op_ms_o, k_ms_o, prod_ms_o = measure()
     assert int(err.item()) == 0
-    algo = ball_group_algorithmic_bytes(PER_GPU_BATCH, BLOCK_POINTS, 1024, 32, CHANNELS)
-    achieved = algo / (k_ms * 1e-3) / 1e9
+
+    def frac(ms):
+        return algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    achieved = algo / (op_ms * 1e-3) / 1e9
     # HBM traffic of that launch cannot be read from inside this process: it is the rocprofv3 --pmc measurement
     # committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), quoted only while the
     # kernel sources are the ones it was measured on
     traffic = None
     try:
-        with open(os.path.join(REPO, "profiles", "r02", "ball_query_pmc.json")) as fh:
+        with open(os.path.join(REPO, "profiles", "r03", "ball_query_pmc.json")) as fh:
             pmc = json.load(fh)
         if pmc.get("source_sha256") == kernel_source_hash():
             traffic = pmc.get("traffic_bytes_per_launch")
@@ -367,25 +468,30 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "switches": active_switches(),
             "config": {"workload": "pointnet2_sem_seg fwd+bwd+Adam, batch=16x4096x%d synthetic %s blocks per GPU, "
                                    "npoint=[1024,256,64,16] nsample=32, 18 classes (BASELINE %s)"
                                    % (step_channels, args.kind, "configs[3], --RGB_OFF" if args.rgb_off else "configs[1]"),
                        "global_batch": world * PER_GPU_BATCH, "points_per_block": BLOCK_POINTS,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "graphs": not args.no_graphs, "prefetch_geometry": not args.no_prefetch},
             "roofline": {"bound": "hbm",
-                         "kernel": "ball_query_binned_kernel = every launch of pn2_ball_query_group_planned "
-                                   "(SA1: N=4096,S=1024,K=32,D=9,B=16, %s)" % args.kind,
+                         "kernel": "operator level: pn2_ball_query_group, (xyz, new_xyz, feats) -> (idx, grouped) in one launch of "
+                                   "ball_query_group_grid_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16, %s)" % args.kind,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": k_ms,
-                         "kernel_ms_single_launch": k_ms_single,
-                         "other_distribution": {"kind": other_kind, "kernel_ms": k_ms_other,
-                                                "frac": algo / (k_ms_other * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "plan_standalone_ms": prod_ms, "plan_with_fps_ms": fps_plan_ms - fps_plain_ms,
-                         "fps_kernel_ms": fps_plain_ms, "self_contained_entry_ms": self_ms,
-                         "frac_with_standalone_plan": algo / ((k_ms + prod_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_with_fps_plan_and_pack": algo / ((k_ms + prod_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_self_contained_entry": algo / (self_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": op_ms, "kernel_ms_single_launch": op_ms_single,
+                         "other_distribution": {"kind": other_kind, "kernel_ms": op_ms_o, "frac": frac(op_ms_o)},
+                         "planned_pair": {
+                             "what": "pn2_ball_plan (binning + row packing, one launch) + pn2_ball_query_group_planned "
+                                     "(ball_query_binned_kernel): the query launch alone is the library's fastest ball kernel, a "
+                                     "caller that uses a plan once pays both",
+                             "query_ms": k_ms, "query_frac": frac(k_ms), "plan_ms": prod_ms, "pair_ms": k_ms + prod_ms,
+                             "pair_frac": frac(k_ms + prod_ms),
+                             "other_distribution": {"kind": other_kind, "query_ms": k_ms_o, "query_frac": frac(k_ms_o),
+                                                    "plan_ms": prod_ms_o, "pair_frac": frac(k_ms_o + prod_ms_o)}},
+                         "fps_kernel_ms": fps_plain_ms},
         }
+        if dp_info is not None:
+            out["data_parallel"] = dp_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -30,6 +30,26 @@ _FUSED_BWD = os.environ.get("PN2_FUSED_BWD", "1") == "1"
 # pn2_bn_relu_out (which re-reads z) for A/B runs.
 _FUSED_OUT = os.environ.get("PN2_FUSED_OUT", "1") == "1"
 _side_streams = {}
+# Test hook (tests/test_hip_gates.py): while a list, every stack forward appends the tensors that define its ReLU /
+# max-pool decisions -- references to what the backward keeps anyway, nothing is copied or launched.
+_GATE_TAPS = None
+
+
+class record_gates:
+    """with mlp.record_gates() as taps: ... -- taps[i] = {"zs": raw conv outputs per layer, "coefs": (scale, shift, mean,
+    invstd) per layer, "argk": winning row of each pooled group (or None), "pool_k": rows per group, "y": the stack's
+    output} of the i-th stack that ran, in call order."""
+
+    def __enter__(self):
+        global _GATE_TAPS
+        self._prev = _GATE_TAPS
+        _GATE_TAPS = []
+        return _GATE_TAPS
+
+    def __exit__(self, *exc):
+        global _GATE_TAPS
+        _GATE_TAPS = self._prev
+        return False
 
 
 def _side_stream(dev):
@@ -275,6 +295,8 @@ class _MLPStack(torch.autograd.Function):
                 rc = lib.pn2_bn_relu_out(_ptr(zs[-1]), rows_out, Co, pool_k, _ptr(coefs[-1][0]), _ptr(coefs[-1][1]), _ptr(y),
                                          _ptr(argk), _stream(dev))
                 _lib.check(rc, "pn2_bn_relu_out")
+        if _GATE_TAPS is not None:
+            _GATE_TAPS.append({"zs": zs, "coefs": coefs, "argk": argk, "pool_k": pool_k, "y": y})
         ctx.training = training
         ctx.pool_k = pool_k
         ctx.argk2, ctx.k2 = argk2, k2

@@ -78,15 +78,10 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, star
     rounds the last dimension up with zero columns."""
     if start is None:
         start = _next_start(xyz.device)
-    B, N, _ = xyz.shape
-    D = 0 if points is None else points.shape[2]
-    if xyz.is_cuda and ops.plan_supported(B, N, npoint) and nsample <= 64:
-        # the FPS kernel leaves the ball query's plan of each block (cell-sorted points, per-centroid runs)
-        fps_idx, new_xyz, plan = ops.farthest_point_sample_plan(xyz, npoint, radius, D, start)
-    else:
-        fps_idx, new_xyz = ops.farthest_point_sample_with_xyz(xyz, npoint, start)
-        plan = None
-    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to, plan=plan)
+    # FPS, then ONE launch from (xyz, new_xyz, points) to (idx, grouped rows): the self-contained operator (a query
+    # plan would be used once here and costs more to build than it saves, DESIGN.md 4.2)
+    fps_idx, new_xyz = ops.farthest_point_sample_with_xyz(xyz, npoint, start)
+    idx, new_points = ops.ball_query_group(radius, nsample, xyz, new_xyz, points, pad_to)
     if returnfps:
         grouped_xyz = ops.index_points(xyz, idx)
         return new_xyz, new_points, grouped_xyz, fps_idx

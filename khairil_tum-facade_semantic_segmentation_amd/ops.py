@@ -230,8 +230,9 @@ def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, p
     grouped = torch.empty((B, S, nsample, ldg), dtype=torch.float32, device=dev) if want_grouped else None
     if plan is not None and not (plan.matches(B, N, S, plan.D, radius, xyz, new_xyz) and (plan.D == D or not want_grouped)):
         plan = None
-    if plan is None and plan_supported(B, N, S) and nsample <= 64:
-        plan = ball_plan(radius, xyz, new_xyz, points if want_grouped else None)
+    # No plan given: the self-contained entry (one launch).  Building a plan for ONE query costs more than it saves
+    # (SA1, B = 16: plan 11.5 us + planned query 8.9 us against 19.3 us self-contained) -- a plan pays
+    # for callers that reuse it, who build it with ball_plan() / farthest_point_sample_plan() and pass it in.
     if plan is not None:
         if want_grouped and ldg == 3 + D and (3 + D) % 4 == 0:
             plan.pack_rows(xyz, points)                       # the fused row stores gather from the plan's packed rows

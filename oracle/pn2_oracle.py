@@ -245,6 +245,10 @@ class OracleNet:
         self.dropout_p = dropout_p
         self.training = False
         self.taps = {}
+        # gate pinning (tests/test_hip_gates.py): {"sa1": {"relu": [mask per layer, oracle layout], "pool": winning k
+        # [B,C,1,S] int64}, ..., "fp1": {"relu": [...]}, "head": {"relu": [mask]}}.  A pinned ReLU is `x * mask`, a pinned
+        # max-pool a gather: the network becomes the piecewise-linear branch somebody else's decisions selected.
+        self.gates = None
 
     def parameters(self):
         return [v for v in self.sd.values() if v.requires_grad]
@@ -257,7 +261,10 @@ class OracleNet:
         w = self.sd["%s.mlp_convs.%d.weight" % (prefix, i)]
         b = self.sd["%s.mlp_convs.%d.bias" % (prefix, i)]
         x = F.conv2d(x, w, b) if w.dim() == 4 else F.conv1d(x, w, b)
-        return F.relu(self._bn(x, "%s.mlp_bns.%d" % (prefix, i)))
+        x = self._bn(x, "%s.mlp_bns.%d" % (prefix, i))
+        if self.gates is not None and prefix in self.gates:
+            return x * self.gates[prefix]["relu"][i].to(x.dtype)
+        return F.relu(x)
 
     def _bn(self, x, p):
         F = self.torch.nn.functional
@@ -284,7 +291,10 @@ class OracleNet:
         x = grouped.permute(0, 3, 2, 1)                                   # [B,C,K,S]
         for i in range(nlayers):
             x = self._conv_bn_relu(x, name, i)
-        x = x.max(dim=2)[0]                                               # [B,C',S]
+        if self.gates is not None and name in self.gates and self.gates[name].get("pool") is not None:
+            x = x.gather(2, self.gates[name]["pool"]).squeeze(2)          # the pinned winner of every group
+        else:
+            x = x.max(dim=2)[0]                                           # [B,C',S]
         return new_xyz, x.permute(0, 2, 1)
 
     def feature_propagation(self, name, nlayers, xyz1, xyz2, points1, points2):
@@ -322,7 +332,8 @@ class OracleNet:
             f = self.feature_propagation(name, len(mlp), xyzs[lvl], xyzs[lvl + 1], skip, f)
             self.taps[name + ".out"] = f
         h = f.permute(0, 2, 1)
-        h = F.relu(self._bn(F.conv1d(h, self.sd["conv1.weight"], self.sd["conv1.bias"]), "bn1"))
+        h = self._bn(F.conv1d(h, self.sd["conv1.weight"], self.sd["conv1.bias"]), "bn1")
+        h = h * self.gates["head"]["relu"][0].to(h.dtype) if (self.gates is not None and "head" in self.gates) else F.relu(h)
         h = F.dropout(h, self.dropout_p, self.training)
         h = F.conv1d(h, self.sd["conv2.weight"], self.sd["conv2.bias"])
         logp = F.log_softmax(h, dim=1).permute(0, 2, 1)
