@@ -543,7 +543,7 @@ def scene_metrics(pred_label, labels, num_classes):
 
 
 def infer_scene(model, data_room, index_room, sample_weight, num_points, num_classes, batch_size=32, num_votes=1,
-                retile=None, group=None, graphs=False, return_votes=False):
+                retile=None, group=None, graphs=False, return_votes=False, engine=None):
     """Whole-scene voting inference (localfunctions.py:375-405): run the network over the scene's
     blocks in sub-batches, vote on the device, return the per-point predicted label tensor.
     `retile`, if given, is called before every vote round after the first to re-draw the blocks
@@ -552,14 +552,14 @@ def infer_scene(model, data_room, index_room, sample_weight, num_points, num_cla
     int32 vote pools are summed with ONE all-reduce per scene (RCCL over xGMI when the backend is "nccl"); every
     rank returns the full label tensor.
     graphs=True (HIP device): the sub-batches run through a BlockInferencer (one replayed graph, the next sub-batch's
-    pyramid prefetched)."""
+    pyramid prefetched); engine = a BlockInferencer of this model and sub-batch shape to reuse (capturing the graph costs
+    about as much as a few hundred blocks: keep one per model across scenes)."""
     import torch
     import torch.distributed as dist
     dev = next(model.parameters()).device
     votes = VotePool(num_points, num_classes, dev)
     model.eval()
-    engine = None
-    if graphs and dev.type == "cuda" and hasattr(model, "compute_geometry"):
+    if engine is None and graphs and dev.type == "cuda" and hasattr(model, "compute_geometry"):
         engine = BlockInferencer(model, batch_size, data_room.shape[2], data_room.shape[1])
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
