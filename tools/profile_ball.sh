@@ -1,8 +1,9 @@
 #!/bin/bash
-# rocprofv3 evidence for the roofline kernel (run on the GPU box from the repo root): kernel-trace stats of bench.py
-# and of the ball-query runner, then FETCH_SIZE / WRITE_SIZE in separate PMC passes.  Output: gpurun_out/prof_r02/.
+# rocprofv3 evidence for the roofline kernels (run on the GPU box from the repo root): kernel-trace stats of bench.py and of
+# the ball-query runner (operator-level entry and planned pair, both distributions), then FETCH_SIZE / WRITE_SIZE and SQ
+# counters in separate PMC passes.  Output: gpurun_out/prof_r03/ (tools/make_profile_json.py turns it into profiles/r03/).
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
-out="$root/gpurun_out/prof_r02"
+out="$root/gpurun_out/prof_r03"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, "rocprof options", program...
@@ -14,11 +15,12 @@ run() {  # name, "rocprof options", program...
   echo "$name done"
 }
 run bench "--kernel-trace --stats" python3 "$root/bench.py" --steps 10 --warmup 5 --no-cpu-baseline
-run ball_cube "--kernel-trace --stats" python3 "$root/tools/run_ball.py" cube 50
-run ball_facade "--kernel-trace --stats" python3 "$root/tools/run_ball.py" facade 50
-run pmc_fetch "--pmc FETCH_SIZE --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
-run pmc_write "--pmc WRITE_SIZE --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
-run pmc_sq1 "--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
-run pmc_sq2 "--pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_BUSY_CYCLES --kernel-trace" python3 "$root/tools/run_ball.py" cube 5
-run control "--kernel-trace --stats" python3 "$root/bench.py" --model pointnet_sem_seg --steps 5 --warmup 3
-ls -la "$out"
+for mode in selfcontained planned; do
+  run ball_${mode}_cube "--kernel-trace --stats" python3 "$root/tools/run_ball.py" cube 50 $mode
+  run ball_${mode}_facade "--kernel-trace --stats" python3 "$root/tools/run_ball.py" facade 50 $mode
+  run pmc_fetch_$mode "--pmc FETCH_SIZE --kernel-trace" python3 "$root/tools/run_ball.py" cube 5 $mode
+  run pmc_write_$mode "--pmc WRITE_SIZE --kernel-trace" python3 "$root/tools/run_ball.py" cube 5 $mode
+  run pmc_sq1_$mode "--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace" python3 "$root/tools/run_ball.py" cube 5 $mode
+  run pmc_sq2_$mode "--pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_BUSY_CYCLES --kernel-trace" python3 "$root/tools/run_ball.py" cube 5 $mode
+done
+ls "$out" | head -60
