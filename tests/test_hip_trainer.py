@@ -226,6 +226,58 @@ def test_two_rank_exchange_on_one_gpu(tmp_path):
     assert np.isfinite(l0).all() and np.isfinite(l1).all() and not np.array_equal(l0, l1)
 
 
+def _dp_epoch_worker(rank, world, port, out):
+    """One rank of a two-rank train_epoch on the shared GPU (gloo): device sampler, augmentation, captured step."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    from make_golden_scene import make_scene
+    from khairil_tum_facade_semantic_segmentation_amd import scene
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+    from khairil_tum_facade_semantic_segmentation_amd.train import SemSegTrainer, draw_batch, train_epoch
+    K = 8
+    rooms = [make_scene(31, 60000), make_scene(32, 40000, extent=(1.6, 1.4, 2.5))]
+    samplers = [scene.DeviceBlockSampler(r[0], r[1], r[2], ["red", "blue", "green"]) for r in rooms]
+    torch.manual_seed(0)
+    model = M.get_model(K, 3).cuda()
+    tr = SemSegTrainer(model, class_weight=torch.ones(K, device="cuda"), graphs=True, prefetch_geometry=True, graph_warmup=1,
+                       augment=False, metrics=True)
+    first = draw_batch(samplers, 4, 3, 0, 0, rank)              # what train_epoch draws for step 0 on this rank
+    tr.prepare(first[0].contiguous(), first[1])
+    tr.broadcast_parameters()
+    e = train_epoch(tr, samplers, 0, steps=3, batch_size=4, seed=3)    # rank taken from the process group
+    torch.cuda.synchronize()
+    np.save(os.path.join(out, "params_rank%d.npy" % rank), tr.flat_adam.flat.detach().cpu().numpy())
+    np.save(os.path.join(out, "first_rank%d.npy" % rank), first[0].cpu().numpy())
+    np.save(os.path.join(out, "loss_rank%d.npy" % rank), np.array([e["loss"], e["seen"]]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_epoch_draws_different_blocks(tmp_path):
+    """train_epoch under a process group: the rank enters the sampler seeds, so the replicas train on
+    DIFFERENT blocks (global batch = world x per-rank batch), and after the gradient all-reduce they hold identical
+    parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_epoch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "params_rank0.npy"), np.load(tmp_path / "params_rank1.npy")
+    assert np.array_equal(p0, p1)
+    f0, f1 = np.load(tmp_path / "first_rank0.npy"), np.load(tmp_path / "first_rank1.npy")
+    assert f0.shape == f1.shape and not np.array_equal(f0, f1)
+    l0, l1 = np.load(tmp_path / "loss_rank0.npy"), np.load(tmp_path / "loss_rank1.npy")
+    assert np.isfinite(l0).all() and np.isfinite(l1).all() and l0[0] != l1[0] and l0[1] == l1[1] == 3 * 4 * 4096
+
+
 def test_schedules_reach_a_captured_step(monkeypatch):
     """The reference loop resets the learning rate and every BatchNorm momentum each epoch
     (localfunctions.py:187-195).  After the step has been captured into hipGraphs both must still take effect:

@@ -81,3 +81,21 @@ def test_best_model_rule():
     assert best.update(0, 0.0, net)                         # `mIoU >= best_iou` with best_iou = 0 (localfunctions.py:310)
     assert best.update(1, 0.31, net) and not best.update(2, 0.30, net) and best.update(3, 0.31, net)
     assert best.epoch == 3 and abs(best.best_iou - 0.31) < 1e-12 and set(best.state) == set(net.state_dict())
+
+
+def test_scene_metrics_follow_the_loop_formulas():
+    """scene.scene_metrics = the per-scene counters of modelTesting (localfunctions.py:409-421, 463-479)."""
+    import numpy as np
+    from khairil_tum_facade_semantic_segmentation_amd.scene import scene_metrics
+    rs = np.random.RandomState(4)
+    K = 6
+    lab = rs.randint(0, K - 1, size=5000)                    # class K-1 never occurs
+    pred = np.where(rs.rand(5000) < 0.7, lab, rs.randint(0, K, size=5000))
+    m = scene_metrics(pred, lab, K)
+    seen = np.array([np.sum(lab == l) for l in range(K)], dtype=float)
+    correct = np.array([np.sum((pred == l) & (lab == l)) for l in range(K)], dtype=float)
+    union = np.array([np.sum((pred == l) | (lab == l)) for l in range(K)], dtype=float)
+    assert np.array_equal(m["class_seen"], seen) and np.array_equal(m["class_correct"], correct) and np.array_equal(m["class_union"], union)
+    iou = correct / (union + 1e-6)
+    assert abs(m["mIoU"] - iou.mean()) < 1e-12 and abs(m["scene_mIoU"] - iou[seen != 0].mean()) < 1e-12
+    assert abs(m["accuracy"] - correct.sum() / (seen.sum() + 1e-6)) < 1e-12
