@@ -87,6 +87,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: its wheel bundles its own HIP runtime (torch/lib/libamdhip64.so).  Loaded before torch, libpn2hip.so
+    # would bind to /opt/rocm's copy instead, and the two runtimes do not share devices or streams: every launch on a torch
+    # stream then fails with hipErrorNoDevice (seen with `build(); smoke()` in one process).  With torch's runtime already in
+    # the process the loader resolves our dependency to it by SONAME.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise Pn2LibraryError(
             "libpn2hip.so not found at %s: the HIP extension is not built and there is no CPU "
