@@ -111,7 +111,23 @@ def gen_sampler():
          feats_first=feats[:, :64].astype(np.float64), labels=labs.astype(np.int8))
 
 
+def gen_labelweights():
+    """calculate_labelweights of the training dataset (sem_seg_training.py:264-278): class weights from the rooms' labels."""
+    import contextlib
+    import io
+    fn = extract(os.path.join(REF, "sem_seg_training.py"), "calculate_labelweights", "TrainCustomDataset")
+    rs = np.random.RandomState(405)
+    K = 8
+    rooms = [rs.choice(K, size=n, p=p) for n, p in ((50000, None), (30000, np.array([.3, .2, .1, .1, .1, .1, .05, .05])),
+                                                    (8000, np.array([.0, .0, .5, .1, .1, .1, .1, .1])))]
+    ds = types.SimpleNamespace(num_classes=K, room_labels=[r.astype(np.float64) for r in rooms])
+    with contextlib.redirect_stdout(io.StringIO()):          # the reference prints its intermediate arrays
+        w = fn(ds)
+    save("scene_labelweights", seed=np.int64(405), sizes=np.array([50000, 30000, 8000]), weights=np.asarray(w, dtype=np.float64))
+
+
 if __name__ == "__main__":
+    gen_labelweights()
     gen_add_vote()
     gen_tiler()
     gen_sampler()

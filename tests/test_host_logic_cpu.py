@@ -73,6 +73,21 @@ def test_label_weights_follow_the_reference_formula():
     assert np.isinf(label_weights([np.array([0, 0, 2])], 3).numpy()[1])      # a class that never occurs: the reference's inf
 
 
+def test_label_weights_equal_the_reference_output(golden):
+    """tests/golden/scene_labelweights.npz = the output of the reference's own calculate_labelweights (run from
+    /root/reference by oracle/make_golden_scene.py) on seeded labels."""
+    import numpy as np
+    from khairil_tum_facade_semantic_segmentation_amd.train import label_weights
+    g = golden("scene_labelweights")
+    rs = np.random.RandomState(int(g["seed"]))
+    K = 8
+    rooms = [rs.choice(K, size=n, p=p) for n, p in ((50000, None), (30000, np.array([.3, .2, .1, .1, .1, .1, .05, .05])),
+                                                    (8000, np.array([.0, .0, .5, .1, .1, .1, .1, .1])))]
+    got = label_weights(rooms, K).numpy()
+    np.testing.assert_allclose(got, g["weights"], rtol=2e-7)          # float32 arithmetic on both sides
+    assert got.dtype == np.float32 and got.min() == 1.0
+
+
 def test_best_model_rule():
     import torch
     from khairil_tum_facade_semantic_segmentation_amd.train import BestModel
