@@ -391,6 +391,16 @@ int pn2_sample_blocks(const double *xyz, const int *order, const int *cell_start
                       const long long *labels, double x0, double y0, double cell, int nx, int ny, int P, int E,
                       double block_size, const double *coord_max, int num_point, int min_points, unsigned long long seed,
                       int B, float *feats, long long *out_labels, int *info, int *sel_idx, pn2_stream_t stream);
+
+/* pn2_sample_blocks over SEVERAL scenes in one launch: the reference's loader mixes rooms inside a batch
+ * (sem_seg_training.py:184-193).  rooms = device table of nrooms 104-byte descriptors {xyz, order, cell_start, extra,
+ * labels (pointers); x0, y0, cell, max_x, max_y, max_z (double); nx, ny, P, pad (int)} -- the per-scene arguments of
+ * pn2_sample_blocks; room_of_block [B] int32 = the room each output block is drawn from: a DEVICE array, or with
+ * room_ids_on_host != 0 a HOST array that travels in the launch's arguments (B <= 256, nrooms <= 256; no upload in
+ * front of the step).  E, block_size, num_point, min_points are common.  Same outputs as pn2_sample_blocks. */
+int pn2_sample_blocks_multi(const void *rooms, int nrooms, const int *room_of_block, int room_ids_on_host, int E,
+                            double block_size, int num_point, int min_points, unsigned long long seed, int B, float *feats,
+                            long long *out_labels, int *info, int *sel_idx, pn2_stream_t stream);
 int pn2_input_blocks(const float *in, int channel_first, int B, int N, int C, const float *angles, float *pts, float *xyz,
                      pn2_stream_t stream);
 int pn2_seg_metrics(const float *logp, const int64_t *target, long long M, int C, long long *counters, pn2_stream_t stream);

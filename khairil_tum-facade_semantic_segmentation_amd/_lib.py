@@ -66,6 +66,7 @@ SIGNATURES = {
     "pn2_adam_step_scattered": [_vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _cd, _cd, _vp],
     "pn2_sample_blocks": [_vp, _vp, _vp, _vp, _vp, _cd, _cd, _cd, _ci, _ci, _ci, _ci, _cd, ctypes.POINTER(ctypes.c_double), _ci, _ci,
                           ctypes.c_ulonglong, _ci, _vp, _vp, _vp, _vp, _vp],
+    "pn2_sample_blocks_multi": [_vp, _ci, _vp, _ci, _ci, _cd, _ci, _ci, ctypes.c_ulonglong, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_tile_windows": [_vp, _vp, _vp, _cd, _cd, _cd, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp],
     "pn2_tile_fill": [_vp, _vp, _vp, _vp, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp, _vp, _vp, _ci, _cl, _ci, _vp,
                       ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp],

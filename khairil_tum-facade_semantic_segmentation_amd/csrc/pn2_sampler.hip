@@ -51,11 +51,10 @@ struct SamplerArgs {
     int *sel;                     // [B][num_point] chosen point indices (nullable)
 };
 
-__global__ __launch_bounds__(SB_THREADS) void sample_blocks_kernel(SamplerArgs a)
+// one workgroup draws output block `b` from the scene described by `a`
+__device__ __forceinline__ void sample_one_block(const SamplerArgs &a, const int b, unsigned long long *list, int &s_cnt, int &s_n)
 {
-    __shared__ unsigned long long list[SB_CAP];
-    __shared__ int s_cnt, s_n;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     int attempt = 0, cnt = 0, centre = 0;
     double cx = 0.0, cy = 0.0, xmin = 0, xmax = 0, ymin = 0, ymax = 0;
     int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
@@ -163,7 +162,73 @@ __global__ __launch_bounds__(SB_THREADS) void sample_blocks_kernel(SamplerArgs a
     }
 }
 
+__global__ __launch_bounds__(SB_THREADS) void sample_blocks_kernel(SamplerArgs a)
+{
+    __shared__ unsigned long long list[SB_CAP];
+    __shared__ int s_cnt, s_n;
+    sample_one_block(a, blockIdx.x, list, s_cnt, s_n);
+}
+
+// Several scenes ("rooms") in ONE launch: the reference's loader mixes rooms inside a batch (room_idxs replicated by point
+// share and shuffled, sem_seg_training.py:184-193), and a launch per room that contributes to a batch put 0.1 ms each in
+// front of every step.  rooms = a device table of per-room descriptors (the scene-specific fields of SamplerArgs),
+// room_of_block [B] = the room every output block is drawn from.
+struct SamplerRoom {
+    const double *xyz;
+    const int *order;
+    const int *cell_start;
+    const float *extra;
+    const long long *labels;
+    double x0, y0, cell;
+    double max_x, max_y, max_z;
+    int nx, ny, P, pad;
+};
+static_assert(sizeof(SamplerRoom) == 104, "room descriptor layout (scene.MultiRoomSampler packs it)");
+
+struct RoomIds { unsigned char id[256]; };          // room of each block, travelling in the kernel arguments (no upload)
+
+__global__ __launch_bounds__(SB_THREADS) void sample_blocks_multi_kernel(SamplerArgs a, const SamplerRoom *__restrict__ rooms,
+                                                                        const int *__restrict__ room_of_block, RoomIds ids, int nrooms)
+{
+    __shared__ unsigned long long list[SB_CAP];
+    __shared__ int s_cnt, s_n;
+    const int r = min(max(room_of_block ? room_of_block[blockIdx.x] : (int)ids.id[blockIdx.x & 255], 0), nrooms - 1);
+    const SamplerRoom m = rooms[r];
+    a.xyz = m.xyz; a.order = m.order; a.cell_start = m.cell_start; a.extra = m.extra; a.labels = m.labels;
+    a.x0 = m.x0; a.y0 = m.y0; a.cell = m.cell; a.nx = m.nx; a.ny = m.ny; a.P = m.P;
+    a.max_x = m.max_x; a.max_y = m.max_y; a.max_z = m.max_z;
+    sample_one_block(a, blockIdx.x, list, s_cnt, s_n);
+}
+
 }  // namespace
+
+PN2_EXPORT int pn2_sample_blocks_multi(const void *rooms, int nrooms, const int *room_of_block, int room_ids_on_host, int E,
+                                       double block_size, int num_point, int min_points, unsigned long long seed, int B, float *feats,
+                                       long long *out_labels, int *info, int *sel_idx, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(rooms); PN2_REQUIRE_PTR(room_of_block); PN2_REQUIRE_PTR(feats); PN2_REQUIRE_PTR(out_labels); PN2_REQUIRE_PTR(info);
+    if (B < 0 || nrooms <= 0 || E < 0 || num_point <= 0 || min_points < 0 || !(block_size > 0.0)) return PN2_ERR_SHAPE;
+    if (num_point > SB_CAP / 2) return PN2_ERR_UNSUPPORTED;
+    if (B == 0) return PN2_OK;
+    SamplerArgs a = {};
+    a.E = E;
+    a.half = block_size / 2.0;
+    a.num_point = num_point; a.min_points = min_points; a.max_attempts = 256; a.seed = seed;
+    a.feats = feats; a.out_labels = out_labels; a.info = info; a.sel = sel_idx;
+    RoomIds ids = {};
+    const int *dev_ids = room_of_block;
+    if (room_ids_on_host) {                            // a HOST array: copied into the launch's arguments
+        if (B > 256 || nrooms > 256) return PN2_ERR_UNSUPPORTED;
+        for (int i = 0; i < B; ++i) {
+            if (room_of_block[i] < 0 || room_of_block[i] >= nrooms) return PN2_ERR_SHAPE;
+            ids.id[i] = (unsigned char)room_of_block[i];
+        }
+        dev_ids = nullptr;
+    }
+    hipLaunchKernelGGL(sample_blocks_multi_kernel, dim3(B), dim3(SB_THREADS), 0, static_cast<hipStream_t>(stream_), a,
+                       static_cast<const SamplerRoom *>(rooms), dev_ids, ids, nrooms);
+    return PN2_LAUNCH_RC();
+}
 
 PN2_EXPORT int pn2_sample_blocks(const double *xyz, const int *order, const int *cell_start, const float *extra,
                                  const long long *labels, double x0, double y0, double cell, int nx, int ny, int P, int E,

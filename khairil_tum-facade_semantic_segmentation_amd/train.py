@@ -492,8 +492,14 @@ def batch_plan(room_sizes, batch_size, seed, epoch, step, rank=0):
 
 
 def draw_batch(samplers, batch_size, seed, epoch, step, rank=0):
-    """One training batch from the device samplers (one scene.DeviceBlockSampler per room) by batch_plan().
+    """One training batch from the device samplers (one scene.DeviceBlockSampler per room, or one scene.MultiRoomSampler
+    over all of them: a single launch per batch) by batch_plan().
     -> (blocks [B,C,N] channel-first view like the loop's points.transpose(2, 1), labels [B,N])"""
+    if hasattr(samplers, "table"):                              # scene.MultiRoomSampler
+        import numpy as np
+        counts, seeds = batch_plan(samplers.sizes, batch_size, seed, epoch, step, rank)
+        f, l, _ = samplers.sample(np.repeat(np.arange(len(counts)), counts), seeds[0])
+        return f.permute(0, 2, 1), l
     counts, seeds = batch_plan([sp.P for sp in samplers], batch_size, seed, epoch, step, rank)
     feats, labels = [], []
     for sp, n, sd in zip(samplers, counts, seeds):
@@ -511,7 +517,9 @@ def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_ra
     on the device: blocks drawn by scene.DeviceBlockSampler (one per room; every block's room drawn in proportion to the
     rooms' point counts, batch_plan()), rotate-z inside the input kernel and accuracy counters on the device (construct
     the trainer with augment=True, metrics=True), the epoch's learning rate and BatchNorm momentum applied graph-safely.
-    The next batch is drawn before the current one is stepped, so the trainer's geometry prefetch runs on it meanwhile.
+    The next batch is drawn before the current one is stepped (ONE sampler launch per batch whatever the number of rooms:
+    scene.MultiRoomSampler), so the trainer's geometry prefetch runs on it meanwhile.  (Drawing two steps ahead on a side
+    stream was measured and dropped: work beside the captured step costs its chain more than the 0.1 ms in front of it.)
     rank (default: this process's rank in the trainer's group) enters the sampling seed: replicas train on different
     blocks.  -> {"loss": mean loss, "accuracy": ..., "lr": ..., "bn_momentum": ...} (one host sync at the end)."""
     lr, momentum = epoch_schedule(epoch, learning_rate, lr_decay, step_size)
@@ -522,6 +530,9 @@ def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_ra
     if rank is None:
         rank = dist.get_rank(trainer.group) if (dist.is_available() and dist.is_initialized()) else 0
 
+    if not hasattr(samplers, "table") and len(samplers) > 1 and samplers[0].dev.type == "cuda":
+        from .scene import MultiRoomSampler
+        samplers = MultiRoomSampler(samplers)                  # one launch per batch instead of one per contributing room
     nxt = draw_batch(samplers, batch_size, seed, epoch, 0, rank)
     loss_sum = None
     for i in range(steps):

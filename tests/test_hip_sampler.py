@@ -118,3 +118,44 @@ def test_sampler_rate_feeds_one_gpu():
     assert int(info[:, 3].sum()) == 0
     print("device block sampler: %.0f blocks/s" % rate)
     assert rate >= 5700.0, rate
+
+
+def test_multi_room_sampler_draws_every_block_from_its_room():
+    """scene.MultiRoomSampler (pn2_sample_blocks_multi): one launch for a batch that mixes rooms -- every block comes from
+    the room it was assigned, with the single-room sampler's block semantics (column around a point of that room, more
+    than 1024 points in it, features by the reference formula with THAT room's maxima)."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    from make_golden_scene import make_scene
+    from khairil_tum_facade_semantic_segmentation_amd import scene
+    from khairil_tum_facade_semantic_segmentation_amd.train import draw_batch
+    rooms = [make_scene(51, 60000), make_scene(52, 40000, extent=(1.6, 1.4, 2.5)), make_scene(53, 30000, extent=(1.2, 1.3, 2.0))]
+    names = ["red", "blue", "green"]
+    samplers = [scene.DeviceBlockSampler(r[0], r[1], r[2], names) for r in rooms]
+    multi = scene.MultiRoomSampler(samplers)
+    assign = np.array([2, 0, 1, 1, 0, 2, 2, 0], dtype=np.int32)
+    feats, labs, info, sel = (t.cpu().numpy() for t in multi.sample(assign, seed=9, want_indices=True))
+    again = multi.sample(assign, seed=9)
+    assert np.array_equal(again[0].cpu().numpy(), feats)
+    assert not np.array_equal(multi.sample(assign, seed=10)[0].cpu().numpy(), feats)
+    for b, r in enumerate(assign):
+        xyz, labels, rgb = rooms[r]
+        assert info[b, 3] == 0 and info[b, 1] > 1024
+        centre = xyz[info[b, 0]]
+        p = xyz[sel[b]]
+        assert np.abs(p[:, 0] - centre[0]).max() <= 0.5 and np.abs(p[:, 1] - centre[1]).max() <= 0.5
+        inside = (np.abs(xyz[:, 0] - centre[0]) <= 0.5) & (np.abs(xyz[:, 1] - centre[1]) <= 0.5)
+        assert inside.sum() == info[b, 1]
+        if info[b, 1] >= 4096:
+            assert np.unique(sel[b]).size == 4096
+        cmax = xyz.max(axis=0)
+        assert np.array_equal(feats[b, :, 0], (p[:, 0] - centre[0]).astype(np.float32))
+        assert np.array_equal(feats[b, :, 2], p[:, 2].astype(np.float32))
+        assert np.array_equal(feats[b, :, 3:6], (p / cmax).astype(np.float32))
+        assert np.array_equal(feats[b, :, 7], (rgb[1][sel[b]] / 255).astype(np.float32))
+        assert np.array_equal(labs[b], labels[sel[b]].astype(np.int64))
+    # the epoch loop's draw: counts per room by batch_plan, one launch
+    x, y = draw_batch(multi, 16, 3, 0, 5, rank=1)
+    assert tuple(x.shape) == (16, 9, 4096) and tuple(y.shape) == (16, 4096)
