@@ -226,6 +226,25 @@ class DeviceBlockSampler:
         return out.cpu().numpy(), self.labels[sel].cpu().numpy()
 
 
+def window_table(cmin, cmax, block_size=1.0, stride=0.5, padding=0.001):
+    """The sliding-window grid of TestCustomDataset.__getitem__ (sem_seg_testing.py:187-201) in the reference's order (y
+    outer, x inner) and float64 arithmetic: -> (windows [W,4] = xmin, xmax, ymin, ymax of the closed, padded window;
+    centres [W,2] = the point the block's x / y are centred on, :220-221)."""
+    bs, st, pad = float(block_size), float(stride), float(padding)
+    gx = int(np.ceil(float(cmax[0] - cmin[0] - bs) / st) + 1)
+    gy = int(np.ceil(float(cmax[1] - cmin[1] - bs) / st) + 1)
+    win, centre = [], []
+    for iy in range(gy):
+        for ix in range(gx):
+            ex = min(cmin[0] + ix * st + bs, cmax[0])
+            sx = ex - bs
+            ey = min(cmin[1] + iy * st + bs, cmax[1])
+            sy = ey - bs
+            win.append((sx - pad, ex + pad, sy - pad, ey + pad))
+            centre.append((sx + bs / 2.0, sy + bs / 2.0))
+    return np.asarray(win, dtype=np.float64).reshape(-1, 4), np.asarray(centre, dtype=np.float64).reshape(-1, 2)
+
+
 class MultiRoomSampler:
     """Several DeviceBlockSamplers behind ONE launch per batch (pn2_sample_blocks_multi): the reference's loader mixes rooms
     inside a batch (room_idxs replicated by point share and shuffled, sem_seg_training.py:184-193), and a launch per
@@ -312,21 +331,7 @@ class DeviceSceneTiler:
             cols.append((e / 255 if name in ("red", "blue", "green") else e).astype(np.float32))      # :233-234
         self.E = len(cols)
         self.extra = torch.from_numpy(np.stack(cols)).to(dev) if cols else None
-        # the window grid of :187-201, in the reference's order (y outer, x inner) and arithmetic
-        bs, st, pad = self.block_size, self.stride, self.padding
-        gx = int(np.ceil(float(self.cmax[0] - self.cmin[0] - bs) / st) + 1)
-        gy = int(np.ceil(float(self.cmax[1] - self.cmin[1] - bs) / st) + 1)
-        win, centre = [], []
-        for iy in range(gy):
-            for ix in range(gx):
-                ex = min(self.cmin[0] + ix * st + bs, self.cmax[0])
-                sx = ex - bs
-                ey = min(self.cmin[1] + iy * st + bs, self.cmax[1])
-                sy = ey - bs
-                win.append((sx - pad, ex + pad, sy - pad, ey + pad))
-                centre.append((sx + bs / 2.0, sy + bs / 2.0))
-        self.windows = np.asarray(win, dtype=np.float64).reshape(-1, 4)
-        self.centres = np.asarray(centre, dtype=np.float64).reshape(-1, 2)
+        self.windows, self.centres = window_table(self.cmin, self.cmax, self.block_size, self.stride, self.padding)
         self._members = None                         # (window table, counts, offsets, member lists): geometry only, built once
 
     def _lib(self):

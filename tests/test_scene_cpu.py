@@ -73,3 +73,26 @@ def test_grid_index_equals_full_scan():
         want = np.where((xy[:, 0] >= a[0]) & (xy[:, 0] <= a[1]) & (xy[:, 1] >= b[0]) & (xy[:, 1] <= b[1]))[0]
         assert np.array_equal(gi.query(a[0], a[1], b[0], b[1]), want)
     assert gi.query(100, 101, 0, 1).size == 0
+
+
+def test_window_table_enumerates_the_reference_windows():
+    """scene.window_table (what the device tiler uploads) = the windows the reference's loop visits: every non-empty
+    window of the host tiler (pinned to the reference golden above) selects exactly the points of the table's row."""
+    rs = np.random.RandomState(8)
+    xyz = rs.uniform(0, 1, size=(20000, 3)) * np.array([2.7, 1.3, 3.0]) + np.array([100.0, -40.0, 2.0])
+    cmin, cmax = xyz.min(axis=0), xyz.max(axis=0)
+    win, centre = scene.window_table(cmin, cmax)
+    gx = int(np.ceil(float(cmax[0] - cmin[0] - 1.0) / 0.5) + 1)
+    gy = int(np.ceil(float(cmax[1] - cmin[1] - 1.0) / 0.5) + 1)
+    assert win.shape == (gx * gy, 4) and centre.shape == (gx * gy, 2)
+    gi = scene.GridIndex(xyz[:, :2], cell=0.25)
+    covered = np.zeros(xyz.shape[0], dtype=bool)
+    for (x0, x1, y0, y1), (cx, cy) in zip(win, centre):
+        assert abs((x1 - x0) - 1.002) < 1e-9 and abs((y1 - y0) - 1.002) < 1e-9           # block_size + 2 * padding
+        assert abs(cx - (x0 + 0.001 + 0.5)) < 1e-12 and abs(cy - (y0 + 0.001 + 0.5)) < 1e-12
+        sel = gi.query(x0, x1, y0, y1)
+        want = np.where((xyz[:, 0] >= x0) & (xyz[:, 0] <= x1) & (xyz[:, 1] >= y0) & (xyz[:, 1] <= y1))[0]
+        assert np.array_equal(sel, want)
+        covered[sel] = True
+    assert covered.all()                                         # the windows tile the whole scene
+    assert win[:, 1].max() == cmax[0] + 0.001 and win[:, 3].max() == cmax[1] + 0.001   # the last window is clamped to the scene
