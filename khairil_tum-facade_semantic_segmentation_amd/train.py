@@ -498,18 +498,27 @@ def draw_batch(samplers, batch_size, seed, epoch, step, rank=0):
     if hasattr(samplers, "table"):                              # scene.MultiRoomSampler
         import numpy as np
         counts, seeds = batch_plan(samplers.sizes, batch_size, seed, epoch, step, rank)
-        f, l, _ = samplers.sample(np.repeat(np.arange(len(counts)), counts), seeds[0])
+        f, l, info = samplers.sample(np.repeat(np.arange(len(counts)), counts), seeds[0])
+        _LAST_DRAW_INFO[0] = info
         return f.permute(0, 2, 1), l
     counts, seeds = batch_plan([sp.P for sp in samplers], batch_size, seed, epoch, step, rank)
-    feats, labels = [], []
+    feats, labels, infos = [], [], []
     for sp, n, sd in zip(samplers, counts, seeds):
         if n:
-            f, l, _ = sp.sample(int(n), seed=sd)
+            f, l, info = sp.sample(int(n), seed=sd)
             feats.append(f)
             labels.append(l)
+            infos.append(info)
     f = feats[0] if len(feats) == 1 else torch.cat(feats)
     l = labels[0] if len(labels) == 1 else torch.cat(labels)
+    _LAST_DRAW_INFO[0] = infos[0] if len(infos) == 1 else torch.cat(infos)
     return f.permute(0, 2, 1), l
+
+
+# info rows [centre, population, attempts, gave-up] of the most recent draw: train_epoch looks at the last batch's once per
+# epoch (it syncs with the host there anyway).  A block whose column never reached the reference's > 1024 points within 256
+# attempts comes back as zeros with the flag set -- the reference's loop would spin forever on such a room.
+_LAST_DRAW_INFO = [None]
 
 
 def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_rate=1e-3, lr_decay=0.7, step_size=10, rank=None):
@@ -541,6 +550,10 @@ def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_ra
         loss_sum = loss.clone() if loss_sum is None else loss_sum + loss
     trainer.drop_prefetched()                              # the last batch was announced as its own successor
     out = {"loss": float(loss_sum) / max(steps, 1), "lr": lr, "bn_momentum": momentum}
+    if _LAST_DRAW_INFO[0] is not None and bool(_LAST_DRAW_INFO[0][:, 3].any()):
+        raise RuntimeError("the block sampler gave up on %d block(s) of the epoch's last batch: no 1 m column with more than 1024 "
+                           "points was found in 256 attempts (a room that sparse makes the reference's sampling loop spin "
+                           "forever, sem_seg_training.py:207-216)" % int(_LAST_DRAW_INFO[0][:, 3].sum()))
     if trainer.metrics is not None:
         out.update(trainer.metrics.read())
     return out
