@@ -249,6 +249,14 @@ int pn2_mlp_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, fl
                      int Ps, int C, double count, float *dgamma, float *dbeta, float *c1, float *c2,
                      pn2_stream_t stream);
 
+/* The slab sums of n layers in one launch (16 per launch): dw[i] [N[i]][Kstore[i]] (the first Kstore <= K columns: a
+ * first layer whose input rows carry zero pad columns has no gradient entries for them), db[i] [N[i]] (nullable) from
+ * partial[i] [P[i]][N[i]][K[i]+1] as pn2_mlp_dw / pn2_mlp_bwd_layer / pn2_head_logits_dropout_backward leave them when
+ * called with dw = NULL.  The bottom layers' weight gradients are needed by nobody before the optimizer: a training
+ * step sums them all at the end of backward (mlp.deferred_weight_sums).  Arrays on the host, read before return. */
+int pn2_mlp_dw_reduce_many(int n, const float *const *partial, const int *P, const int *N, const int *K, const int *Kstore,
+                           float *const *dw, float *const *db, pn2_stream_t stream);
+
 /* BatchNorm+ReLU backward statistics of the top layer of a stack: partial
  * [pn2_bn_bwd_reduce_partials(rows)][2][C] sums of gh and gh*xh over rows (rows = M, or the
  * M/pool_k pooled rows with argk).  pn2_bn_bwd_finalize turns partials (from here or from the

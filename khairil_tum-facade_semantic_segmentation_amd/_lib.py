@@ -46,6 +46,7 @@ SIGNATURES = {
     "pn2_mlp_bwd_layer": [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp,
                           _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _vp],
     "pn2_mlp_bwd_post": [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _ci, _cd, _vp, _vp, _vp, _vp, _vp],
+    "pn2_mlp_dw_reduce_many": [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_bn_bwd_reduce_partials": [_cl],
     "pn2_bn_bwd_reduce": [_vp, _ci, _vp, _ci, _cl, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_bn_bwd_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _vp, _vp, _vp],

@@ -594,7 +594,7 @@ PN2_EXPORT int pn2_head_logits_dropout_backward(const float *glogp, const float 
     if (drop_p < 0.f || drop_p > 1.f) return PN2_ERR_SHAPE;
     const DropArgs drop = make_drop(drop_seed, drop_p);
     PN2_REQUIRE_PTR(glogp); PN2_REQUIRE_PTR(logp); PN2_REQUIRE_PTR(y); PN2_REQUIRE_PTR(w);
-    PN2_REQUIRE_PTR(partial); PN2_REQUIRE_PTR(dw);
+    PN2_REQUIRE_PTR(partial);                        // dw NULL: slabs only (summed later, pn2_mlp_dw_reduce_many)
     if (M <= 0 || K <= 0 || C <= 0 || ldy < K || (gy && ldgy < K)) return PN2_ERR_SHAPE;
     if (K > HD_KMAX || C > HD_CMAX || (K & 3) || (ldy & 3) || !aligned16(y) || !aligned16(w)) return PN2_ERR_UNSUPPORTED;
     if (gy && ((ldgy & 3) || !aligned16(gy))) return PN2_ERR_UNSUPPORTED;
@@ -607,7 +607,7 @@ PN2_EXPORT int pn2_head_logits_dropout_backward(const float *glogp, const float 
         hipLaunchKernelGGL(head_logits_backward_kernel, dim3(P), dim3(HD_THREADS), 0, s, glogp, logp, y, ldy, w, gy, ldgy,
                            partial, M, K, C, drop);
     int rc = PN2_LAUNCH_RC();
-    if (rc != PN2_OK) return rc;
+    if (rc != PN2_OK || !dw) return rc;
     return pn2::launch_dw_reduce(partial, P, C, K, dw, db, s);       // same slab layout as the MLP's dW partials
 }
 

@@ -1425,35 +1425,101 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw128_kernel(DwArgs p)
     }
 }
 
-// dW[n][k] = sum_p partial[p][n][k] (k < K), db[n] = sum_p partial[p][n][K]; fixed order:
-// 32 elements x 8 partial slices per workgroup, slices combined in order through LDS.
-__device__ __forceinline__ void dw_reduce_block(int block, const float *__restrict__ partial, int P, int N, int K,
-                                                float *__restrict__ dw, float *__restrict__ db, float (*sS)[33])
+// dW[n][k] = sum_p partial[p][n][k] (k < Kst <= K), db[n] = sum_p partial[p][n][K]; fixed order.  A 1024-thread workgroup
+// is SL = 1 << sl_shift slices x 1024/SL lanes; a lane owns four consecutive elements of the flattened [N][K+1] slab (one:
+// `vec` false, slabs whose size or address is not a multiple of four floats), slice s sums partials s, s + SL, ... with up to
+// eight loads in flight, the slices are combined in order through LDS.  SL grows with P (dw_reduce_shape): few partials
+// (the deep levels' 8-16 slabs of up to 200 000 elements) need lanes, many partials (512 slabs of a 32 x 13 layer) need
+// slices -- the first form of this routine (32 elements x 32 slices whatever P) spent 13 us on 8 slabs.
+// Kst = columns of dw that exist ([N][Kst]): a first layer whose input rows carry zero pad columns has no gradient
+// entries for them.
+struct DwReduceShape { int sl_shift, vec, blocks; };
+inline DwReduceShape dw_reduce_shape(const float *partial, int P, int N, int K)
 {
-    const int Kout = K + 1;
-    const int el = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int e = block * 32 + el;
-    const size_t stride = (size_t)N * Kout;
-    float s = 0.f;
-    if (e < N * Kout) {
-        float s0 = 0.f, s1 = 0.f;
-        strided_sum_any(partial + e, stride, py, P, s0, s1);
-        s = s0 + s1;
-    }
-    sS[py][el] = s;
-    __syncthreads();
-    if (py != 0 || e >= N * Kout) return;
-    for (int i = 1; i < 32; ++i) s += sS[i][el];
-    const int n = e / Kout, k = e - n * Kout;
-    if (k < K) dw[(size_t)n * K + k] = s;
-    else if (db) db[n] = s;
+    DwReduceShape r;
+    const long long total = (long long)N * (K + 1);
+    r.vec = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+    r.sl_shift = 0;
+    while (r.sl_shift < 5 && (P >> r.sl_shift) > 8) ++r.sl_shift;
+    const long long per_wg = (long long)(1024 >> r.sl_shift) * (r.vec ? 4 : 1);
+    r.blocks = (int)((total + per_wg - 1) / per_wg);
+    return r;
 }
 
-__global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K,
+__device__ __forceinline__ void dw_reduce_block(int block, const float *__restrict__ partial, int P, int N, int K, int Kst,
+                                                int sl_shift, int vec, float *__restrict__ dw, float *__restrict__ db, float4 *sbuf)
+{
+    const int Kout = K + 1;
+    const int total = N * Kout;
+    const int SL = 1 << sl_shift, lanes = 1024 >> sl_shift;
+    const int q = threadIdx.x & (lanes - 1), sl = threadIdx.x >> (10 - sl_shift);
+    const int e0 = (block * lanes + q) * (vec ? 4 : 1);
+    const size_t stride = (size_t)total;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e0 < total) {
+        const float *src = partial + e0;
+        for (int p0 = sl; p0 < P; p0 += 8 * SL) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)min(p0 + u * SL, P - 1) * stride;
+                if (vec) v[u] = *reinterpret_cast<const float4 *>(src + o);
+                else v[u] = make_float4(src[o], 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + u * SL < P) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    if (SL > 1) {
+        sbuf[sl * lanes + q] = acc;
+        __syncthreads();
+        if (sl != 0) return;
+        for (int i = 1; i < SL; ++i) {
+            const float4 t = sbuf[i * lanes + q];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+    }
+    if (e0 >= total) return;
+    if (Kst < 0) Kst = K;
+    const float out[4] = {acc.x, acc.y, acc.z, acc.w};
+    int n = e0 / Kout, k = e0 - n * Kout;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u == 0 || vec) {
+            if (k < K) { if (k < Kst) dw[(size_t)n * Kst + k] = out[u]; }
+            else if (db) db[n] = out[u];
+            if (++k == Kout) { k = 0; ++n; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void dw_reduce_kernel(const float *__restrict__ partial, int P, int N, int K, int sl_shift, int vec,
                                                         float *__restrict__ dw, float *__restrict__ db)
 {
-    __shared__ float sS[32][33];
-    dw_reduce_block(blockIdx.x, partial, P, N, K, dw, db, sS);
+    __shared__ __attribute__((aligned(16))) float4 sbuf[1024];
+    dw_reduce_block(blockIdx.x, partial, P, N, K, K, sl_shift, vec, dw, db, sbuf);
+}
+
+// The slab sums of SEVERAL layers in one launch (the bottom layers of all stacks, whose sums nothing but the optimizer
+// waits for: pn2_mlp_dw_reduce_many).  Jobs by value: a captured launch keeps them.
+constexpr int DW_MANY_MAX = 16;
+struct DwReduceMany {
+    int n;
+    int first[DW_MANY_MAX + 1];                 // first workgroup of job j; first[n] = grid size
+    const float *partial[DW_MANY_MAX];
+    float *dw[DW_MANY_MAX], *db[DW_MANY_MAX];
+    int P[DW_MANY_MAX], N[DW_MANY_MAX], K[DW_MANY_MAX], Kst[DW_MANY_MAX];
+    unsigned char sl_shift[DW_MANY_MAX], vec[DW_MANY_MAX];
+};
+
+__global__ __launch_bounds__(1024) void dw_reduce_many_kernel(DwReduceMany m)
+{
+    __shared__ __attribute__((aligned(16))) float4 sbuf[1024];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    dw_reduce_block((int)blockIdx.x - m.first[j], m.partial[j], m.P[j], m.N[j], m.K[j], m.Kst[j], m.sl_shift[j], m.vec[j], m.dw[j],
+                    m.db[j], sbuf);
 }
 
 // Column partial sums of gh and gh*xh over rows for the TOP layer of a stack (the inner layers
@@ -1579,17 +1645,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
 // Both reductions that follow a layer's backward kernel in ONE launch (every launch costs a few
 // microseconds of fixed time): blocks [0, nred) sum the dW slabs, the rest finalize the BatchNorm
 // statistics of the layer below.
-__global__ __launch_bounds__(1024) void bwd_post_kernel(const float *__restrict__ dw_partial, int P, int N, int K,
-                                                       float *__restrict__ dw, float *__restrict__ db, int nred,
+__global__ __launch_bounds__(1024) void bwd_post_kernel(const float *__restrict__ dw_partial, int P, int N, int K, int sl_shift,
+                                                       int vec, float *__restrict__ dw, float *__restrict__ db, int nred,
                                                        const float *__restrict__ stat_partial, int Ps, int C, double count,
                                                        float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                        float *__restrict__ c1, float *__restrict__ c2)
 {
-    __shared__ double sS[32][33], sQ[32][33];
+    __shared__ __attribute__((aligned(16))) double sbuf[2 * 32 * 33];
+    static_assert(sizeof(sbuf) >= 1024 * sizeof(float4), "slice combine buffer");
     if ((int)blockIdx.x < nred)
-        dw_reduce_block(blockIdx.x, dw_partial, P, N, K, dw, db, reinterpret_cast<float (*)[33]>(sQ));
+        dw_reduce_block(blockIdx.x, dw_partial, P, N, K, K, sl_shift, vec, dw, db, reinterpret_cast<float4 *>(sbuf));
     else
-        bn_bwd_finalize_block(blockIdx.x - nred, stat_partial, Ps, C, count, dgamma, dbeta, c1, c2, sS, sQ);
+        bn_bwd_finalize_block(blockIdx.x - nred, stat_partial, Ps, C, count, dgamma, dbeta, c1, c2,
+                              reinterpret_cast<double (*)[33]>(sbuf), reinterpret_cast<double (*)[33]>(sbuf + 32 * 33));
 }
 
 inline unsigned grid_for(long long total, int threads)
@@ -1879,18 +1947,49 @@ PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
 
 int pn2::launch_dw_reduce(const float *partial, int P, int N, int K, float *dw, float *db, hipStream_t stream)
 {
-    const int total = N * (K + 1);
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(1024), 0, stream, partial, P, N, K, dw, db);
+    const DwReduceShape r = dw_reduce_shape(partial, P, N, K);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(r.blocks), dim3(1024), 0, stream, partial, P, N, K, r.sl_shift, r.vec, dw, db);
     return PN2_LAUNCH_RC();
 }
 
 int pn2::launch_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial, int Ps,
                          int C, double count, float *dgamma, float *dbeta, float *c1, float *c2, hipStream_t stream)
 {
-    const int nred = (N * (K + 1) + 31) / 32, nfin = (C + 31) / 32;
-    hipLaunchKernelGGL(bwd_post_kernel, dim3(nred + nfin), dim3(1024), 0, stream, dw_partial, P, N, K, dw, db, nred, stat_partial, Ps,
-                       C, count, dgamma, dbeta, c1, c2);
+    const DwReduceShape r = dw_reduce_shape(dw_partial, P, N, K);
+    const int nred = r.blocks, nfin = (C + 31) / 32;
+    hipLaunchKernelGGL(bwd_post_kernel, dim3(nred + nfin), dim3(1024), 0, stream, dw_partial, P, N, K, r.sl_shift, r.vec, dw, db, nred,
+                       stat_partial, Ps, C, count, dgamma, dbeta, c1, c2);
     return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_mlp_dw_reduce_many(int n, const float *const *partial, const int *P, const int *N, const int *K,
+                                      const int *Kstore, float *const *dw, float *const *db, pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(partial); PN2_REQUIRE_PTR(P); PN2_REQUIRE_PTR(N); PN2_REQUIRE_PTR(K); PN2_REQUIRE_PTR(Kstore);
+    PN2_REQUIRE_PTR(dw); PN2_REQUIRE_PTR(db);
+    if (n < 0) return PN2_ERR_SHAPE;
+    for (int j0 = 0; j0 < n; j0 += DW_MANY_MAX) {
+        DwReduceMany m;
+        m.n = n - j0 < DW_MANY_MAX ? n - j0 : DW_MANY_MAX;
+        long long blocks = 0;
+        for (int j = 0; j < DW_MANY_MAX; ++j) {
+            const int i = j0 + (j < m.n ? j : m.n - 1);
+            if (!partial[i] || !dw[i]) return PN2_ERR_NULL;
+            if (P[i] <= 0 || N[i] <= 0 || K[i] <= 0 || Kstore[i] <= 0 || Kstore[i] > K[i]) return PN2_ERR_SHAPE;
+            m.partial[j] = partial[i]; m.dw[j] = dw[i]; m.db[j] = db[i];
+            m.P[j] = P[i]; m.N[j] = N[i]; m.K[j] = K[i]; m.Kst[j] = Kstore[i];
+            const DwReduceShape r = dw_reduce_shape(partial[i], P[i], N[i], K[i]);
+            m.sl_shift[j] = (unsigned char)r.sl_shift; m.vec[j] = (unsigned char)r.vec;
+            m.first[j] = (int)blocks;
+            if (j < m.n) blocks += r.blocks;
+            if (blocks > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
+        }
+        m.first[DW_MANY_MAX] = (int)blocks;
+        for (int j = m.n; j < DW_MANY_MAX; ++j) m.first[j] = (int)blocks;
+        hipLaunchKernelGGL(dw_reduce_many_kernel, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), m);
+        if (const int rc = PN2_LAUNCH_RC()) return rc;
+    }
+    return PN2_OK;
 }
 
 PN2_EXPORT int pn2_mlp_bwd_post(const float *dw_partial, int P, int N, int K, float *dw, float *db, const float *stat_partial,
@@ -1948,9 +2047,7 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
     }
     int rc = PN2_LAUNCH_RC();
     if (rc != PN2_OK || dw == nullptr) return rc;         // dw NULL: slabs only, reduced later by pn2_mlp_bwd_post
-    const int total = N * (K + 1);
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 31) / 32), dim3(1024), 0, stream, partial, P, N, K, dw, db);
-    return PN2_LAUNCH_RC();
+    return pn2::launch_dw_reduce(partial, P, N, K, dw, db, stream);
 }
 
 PN2_EXPORT int pn2_bn_bwd_reduce_partials(long long rows)

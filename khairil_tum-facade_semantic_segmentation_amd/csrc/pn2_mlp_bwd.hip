@@ -1012,7 +1012,8 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
 {
     PN2_REQUIRE_PTR(g); PN2_REQUIRE_PTR(z); PN2_REQUIRE_PTR(scale); PN2_REQUIRE_PTR(shift); PN2_REQUIRE_PTR(mean);
     PN2_REQUIRE_PTR(invstd); PN2_REQUIRE_PTR(c1); PN2_REQUIRE_PTR(c2); PN2_REQUIRE_PTR(w); PN2_REQUIRE_PTR(x);
-    PN2_REQUIRE_PTR(dw_partial); PN2_REQUIRE_PTR(dw);
+    PN2_REQUIRE_PTR(dw_partial);
+    if (!dw && c1_below) return PN2_ERR_NULL;        // dw NULL: slabs only (summed later, pn2_mlp_dw_reduce_many)
     if (M <= 0 || N <= 0 || K <= 0 || (argk && pool_k <= 0) || ldw < K || ldx < K || ldz < N) return PN2_ERR_SHAPE;
     const bool masked = ascale != nullptr;
     if (masked && (!ashift || !amean || !ainvstd)) return PN2_ERR_NULL;
@@ -1055,5 +1056,6 @@ PN2_EXPORT int pn2_mlp_bwd_layer(const float *g, int ldg, const float *z, int ld
     if (c1_below)                                    // BatchNorm-backward constants of the layer below, same launch
         return pn2::launch_bwd_post(dw_partial, P, N, K, dw, db, stat_partial, P, K, (double)M, dgamma_below, dbeta_below, c1_below,
                                     c2_below, stream);
+    if (!dw) return PN2_OK;
     return pn2::launch_dw_reduce(dw_partial, P, N, K, dw, db, stream);
 }

@@ -50,10 +50,12 @@ class _HeadLogits(torch.autograd.Function):
         db = torch.empty(C, **f32) if ctx.has_bias else None
         with torch.cuda.device(dev):
             rc = lib.pn2_head_logits_dropout_backward(_ptr(g), _ptr(logp), _ptr(y), y.stride(0), _ptr(w2), _ptr(gy),
-                                                      0 if gy is None else gy.stride(0), _ptr(part), _ptr(dw), _ptr(db),
+                                                      0 if gy is None else gy.stride(0), _ptr(part), None, None,
                                                       M, K, C, _ptr(ctx.seed), ctx.drop_p, _stream(dev))
         _lib.check(rc, "pn2_head_logits_dropout_backward")
-        return gy, dw.view(ctx.wshape), db, None, None
+        from . import mlp
+        mlp.finish_slabs(part, P, C, K, K, dw, db)       # summed now, or with the stacks' bottom layers at the end of backward
+        return gy, dw.view(ctx.wshape), None if db is None else db.view(-1), None, None
 
 
 def head_logits(y, weight, bias, drop_p=0.0, seed=None):

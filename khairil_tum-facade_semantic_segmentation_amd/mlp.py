@@ -163,9 +163,77 @@ def refresh_eval_coefficients(module):
                 _eval_coefficients(lib, dev, m, m.weight, m.bias)
 
 
+_DEFERRED = None            # list of pending slab sums while a deferred_weight_sums() block is open
+
+
+def reduce_slabs(jobs, dev):
+    """jobs: (partial [P,N,K+1], P, N, K, Kstore, dw [N,Kstore], db [N] or None) -> one pn2_mlp_dw_reduce_many launch per 16."""
+    import ctypes
+    if not jobs:
+        return
+    n = len(jobs)
+    vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn2_mlp_dw_reduce_many(
+            n, vp(*[j[0].data_ptr() for j in jobs]), ci(*[j[1] for j in jobs]), ci(*[j[2] for j in jobs]),
+            ci(*[j[3] for j in jobs]), ci(*[j[4] for j in jobs]), vp(*[j[5].data_ptr() for j in jobs]),
+            vp(*[None if j[6] is None else j[6].data_ptr() for j in jobs]), _stream(dev))
+    _lib.check(rc, "pn2_mlp_dw_reduce_many")
+
+
+class deferred_weight_sums:
+    """Inside the block, the weight gradients of the BOTTOM layer of every stack (and of the head's last conv) stay as
+    per-workgroup slabs; leaving the block sums all of them in one launch.  Nothing in a backward pass reads those
+    gradients -- only the optimizer does -- so a training step wraps `loss.backward()` in this (train.SemSegTrainer): nine
+    launches of the step become one.  The gradient TENSORS are handed to autograd at once and filled at the end of the
+    block: only valid while every `.grad` is None on entry (autograd then keeps the tensor it is given; an accumulating
+    `grad += g` would read it too early), which the block checks for the parameters it is given."""
+
+    def __init__(self, params=None):
+        self.params = params
+
+    def __enter__(self):
+        global _DEFERRED
+        self.outer = _DEFERRED is not None
+        if not self.outer:
+            if self.params is not None and any(p.grad is not None for p in self.params):
+                self.outer = True                        # somebody accumulates: stay with immediate sums
+            else:
+                _DEFERRED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        if self.outer:
+            return False
+        jobs, _DEFERRED = _DEFERRED, None
+        if exc[0] is None and jobs:
+            reduce_slabs(jobs, jobs[0][0].device)
+            if self.params is not None:
+                # autograd keeps a gradient it is handed only while nobody else holds the same tensor object (backward
+                # returns VIEWS of dw / db for that reason); a copy made before the sums would hold unfinished values
+                held = {p.grad.data_ptr() for p in self.params if p.grad is not None}
+                for j in jobs:
+                    if j[5].data_ptr() not in held or (j[6] is not None and j[6].data_ptr() not in held):
+                        raise RuntimeError("deferred_weight_sums: autograd copied a weight gradient before it was summed "
+                                           "(set PN2_DEFER_DW=0)")
+        return False
+
+
+def finish_slabs(partial, P, N, K, Kstore, dw, db):
+    """Sum one layer's slabs now, or at the end of the open deferred_weight_sums() block."""
+    job = (partial, P, N, K, Kstore, dw, db)
+    if _DEFERRED is not None:
+        _DEFERRED.append(job)
+    else:
+        reduce_slabs([job], partial.device)
+
+
 class _MLPStack(torch.autograd.Function):
     """y = stack(x1 | x2).  args: bns (list of nn.BatchNorm modules, for running stats / mode),
-    pool_k (0 = no pooling), x1 [M,K1], x2 [M,K2] or None, then per layer conv_w, conv_b, bn_w, bn_b."""
+    pool_k (0 = no pooling), x1 [M,K1], x2 [M,K2] or None, then per layer conv_w, conv_b, bn_w, bn_b.  The first
+    conv's weight may have fewer columns than the rows (zero pad columns behind the real ones, 16-byte aligned rows): it is
+    padded here, and its gradient comes back in its own shape."""
 
     @staticmethod
     def forward(ctx, bns, pool_k, x1, x2, *params):
@@ -180,12 +248,14 @@ class _MLPStack(torch.autograd.Function):
         inference = not training and not any(ctx.needs_input_grad)
         f32 = dict(dtype=torch.float32, device=dev)
         zs, coefs = [], []
-        y = argk = None
+        y = argk = wpad = None
         with torch.cuda.device(dev):
             for l in range(L):
                 w, b, gamma, beta = params[4 * l:4 * l + 4]
                 Co = w.shape[0]
                 w2 = w.reshape(Co, -1)
+                if l == 0 and w2.shape[1] < K1 + K2:
+                    w2 = wpad = _pad_cols(w2, K1 + K2)
                 z = None if (inference and l == L - 1 and _FUSED_OUT and pool_k == 32 and Co % 4 == 0 and M % 32 == 0) \
                     else torch.empty((M, Co), **f32)
                 P = lib.pn2_mlp_gemm_max_partials(M)
@@ -305,6 +375,7 @@ class _MLPStack(torch.autograd.Function):
         ctx.argk = argk
         ctx.coefs = coefs
         ctx.zs = zs
+        ctx.wpad = wpad
         ctx.save_for_backward(x1, *((x2,) if x2 is not None else ()), *params)
         return y
 
@@ -347,6 +418,9 @@ class _MLPStack(torch.autograd.Function):
                 w, b = params[4 * l], params[4 * l + 1]
                 Co = w.shape[0]
                 w2 = w.reshape(Co, -1)
+                cin = w2.shape[1]                       # columns of the gradient; Ci = columns of the rows
+                if l == 0 and ctx.wpad is not None:
+                    w2 = ctx.wpad
                 Ci = w2.shape[1]
                 z = zs[l]
                 sc, sh, mu, istd = coefs[l]
@@ -370,7 +444,7 @@ class _MLPStack(torch.autograd.Function):
                 if Pf:
                     pk = pool_k if g_argk is not None else 0
                     wpart = torch.empty((Pf, Co, Ci + 1), **f32)
-                    dw, db = torch.empty((Co, Ci), **f32), torch.empty(Co, **f32)
+                    dw, db = torch.empty((Co, cin), **f32), torch.empty(Co, **f32)
                     if l > 0:
                         xin, below = zs[l - 1], coefs[l - 1]
                         gp = torch.empty((M, Ci), **f32)
@@ -384,11 +458,13 @@ class _MLPStack(torch.autograd.Function):
                     rc = lib.pn2_mlp_bwd_layer(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(g_argk), pk, _ptr(sc), _ptr(sh),
                                                _ptr(mu), _ptr(istd), _ptr(c1), _ptr(c2), _ptr(w2), w2.stride(0), _ptr(xin),
                                                xin.stride(0), _ptr(below[0]), _ptr(below[1]), _ptr(below[2]), _ptr(below[3]),
-                                               _ptr(gp), 0 if gp is None else gp.stride(0), _ptr(spart), _ptr(wpart), _ptr(dw),
-                                               _ptr(db), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), _ptr(nxt[3]), M, Co, Ci,
-                                               _stream(dev))
+                                               _ptr(gp), 0 if gp is None else gp.stride(0), _ptr(spart), _ptr(wpart),
+                                               _ptr(dw) if l > 0 else None, _ptr(db), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]),
+                                               _ptr(nxt[3]), M, Co, Ci, _stream(dev))
                     _lib.check(rc, "pn2_mlp_bwd_layer")
-                    grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db
+                    if l == 0:                           # the bottom layer's slabs: summed now or at the end of backward
+                        finish_slabs(wpart, Pf, Co, Ci, cin, dw, db)
+                    grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db.view(-1)
                     if l > 0:
                         g, g_argk, part, P = gp, None, spart, Pf
                         carried = nxt
@@ -398,7 +474,7 @@ class _MLPStack(torch.autograd.Function):
                 # dW, db
                 Pw = lib.pn2_mlp_dw_partials(M, Co, Ci)
                 wpart = torch.empty((Pw, Co, Ci + 1), **f32)
-                dw, db = torch.empty((Co, Ci), **f32), torch.empty(Co, **f32)
+                dw, db = torch.empty((Co, cin), **f32), torch.empty(Co, **f32)
                 if l == 0:
                     a1, a2, ak1, ak2, asc, ash = x1, x2, K1, K2, None, None
                 else:
@@ -412,12 +488,18 @@ class _MLPStack(torch.autograd.Function):
                 # with a layer below and no side stream, the slabs stay unreduced here and are summed in the launch
                 # that also finalizes the statistics the dX GEMM is about to produce (pn2_mlp_bwd_post)
                 defer = l > 0 and side is None
+                late = l == 0                           # bottom layer: pn2_mlp_dw_reduce_many, now or at the end of backward
                 rc = lib.pn2_mlp_dw(_ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(g_argk), pool_k if g_argk is not None else 0,
                                     _ptr(sc), _ptr(sh), _ptr(mu), _ptr(istd), _ptr(c1), _ptr(c2), _ptr(a1), a1.stride(0), ak1,
                                     _ptr(a2), 0 if a2 is None else a2.stride(0), ak2, _ptr(asc), _ptr(ash), M, Co, _ptr(wpart),
-                                    None if defer else _ptr(dw), _ptr(db), dw_stream)
+                                    None if (defer or late) else _ptr(dw), _ptr(db), dw_stream)
                 _lib.check(rc, "pn2_mlp_dw")
-                grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db
+                if late and side is not None:
+                    with torch.cuda.stream(side):
+                        reduce_slabs([(wpart, Pw, Co, Ci, cin, dw, db)], dev)
+                elif late:
+                    finish_slabs(wpart, Pw, Co, Ci, cin, dw, db)
+                grads[4 * l], grads[4 * l + 1] = dw.view(w.shape), db.view(-1)
                 # dX (= gradient w.r.t. the activation below), masked + reduced for the layer below
                 if l > 0:
                     zp = zs[l - 1]
@@ -451,32 +533,17 @@ class _MLPStack(torch.autograd.Function):
         return (None, None, gx1, gx2) + tuple(grads)
 
 
-class _PadCols(torch.autograd.Function):
-    """w [Co, cin] -> [Co, kin] with zero columns behind cin (one launch; F.pad and its backward cost five)."""
-
-    @staticmethod
-    def forward(ctx, w, kin):
-        dev = _dev(w)
-        lib = _lib.load()
-        Co, cin = w.shape
-        out = torch.empty((Co, kin), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.pn2_copy_pad_cols(_ptr(w), w.stride(0), cin, _ptr(out), kin, kin, Co, _stream(dev))
-        _lib.check(rc, "pn2_copy_pad_cols")
-        ctx.cin = cin
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        dev = g.device
-        lib = _lib.load()
-        g = g.contiguous()
-        Co, kin = g.shape
-        out = torch.empty((Co, ctx.cin), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.pn2_copy_pad_cols(_ptr(g), kin, kin, _ptr(out), ctx.cin, ctx.cin, Co, _stream(dev))
-        _lib.check(rc, "pn2_copy_pad_cols")
-        return out, None
+def _pad_cols(w, kin):
+    """w [Co, cin] -> [Co, kin] with zero columns behind cin (one launch)."""
+    dev = _dev(w)
+    lib = _lib.load()
+    w = w.detach()
+    Co, cin = w.shape
+    out = torch.empty((Co, kin), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn2_copy_pad_cols(_ptr(w), w.stride(0), cin, _ptr(out), kin, kin, Co, _stream(dev))
+    _lib.check(rc, "pn2_copy_pad_cols")
+    return out
 
 
 def mlp_stack(x1, x2, convs, bns, pool_k=0):
@@ -496,14 +563,11 @@ def mlp_stack(x1, x2, convs, bns, pool_k=0):
             raise NotImplementedError("mlp_stack expects conv bias and affine BatchNorm (as the reference builds them)")
         w = conv.weight
         if l == 0:
-            # rows may carry zero pad columns (16-byte aligned rows): pad the weight to match; autograd
-            # slices the gradient back (tiny tensors, two extra kernels per stack)
+            # rows may carry zero pad columns (16-byte aligned rows): the stack pads the weight to match and returns
+            # the gradient in the weight's own shape
             cin = w.shape[1]
             kin = x1.shape[1] + (0 if x2 is None else x2.shape[1])
             if kin < cin or (kin > cin and x2 is not None):
                 raise ValueError("input rows have %d columns, first conv expects %d" % (kin, cin))
-            w = w.reshape(w.shape[0], cin)
-            if kin > cin:
-                w = _PadCols.apply(w.contiguous(), kin)
         params += [w, conv.bias, bn.weight, bn.bias]
     return _MLPStack.apply(list(bns), pool_k, x1, x2, *params)

@@ -5,12 +5,15 @@ when the backend is "nccl") of a flat fp32 gradient buffer per step (SURVEY.md 8
 The reference has no distributed code (single process, sem_seg_training.py:374); the step body
 restates localfunctions.py:203-218: zero_grad -> forward -> nll_loss(weight) -> backward -> Adam
 (sem_seg_training.py:576-582).  BatchNorm statistics stay rank-local (no SyncBN upstream)."""
+import contextlib
 import os
 
 import torch
 import torch.distributed as dist
 
 from . import head, mlp
+
+_DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 
 def rotate_z_(blocks_cf, angles=None):
@@ -319,7 +322,10 @@ class SemSegTrainer:
             pred, _ = self.model(blocks_cf) if geometry is None else self.model(blocks_cf, geometry=geometry)
         loss = self.criterion(pred.reshape(-1, pred.shape[-1]), target.reshape(-1), None, self.class_weight)
         # the seed of backward is a resident 1.0 (loss.backward() alone fills a fresh ones_like every step: one launch)
-        loss.backward(self._unit if (self._unit is not None and loss.dim() == 0 and loss.dtype == self._unit.dtype) else None)
+        # the weight gradients of every stack's bottom layer are summed in ONE launch at the end of backward (nobody reads
+        # them before the optimizer; every .grad is None here, so autograd keeps the tensors it is handed)
+        with (mlp.deferred_weight_sums(self.grads.params) if _DEFER_DW else contextlib.nullcontext()):
+            loss.backward(self._unit if (self._unit is not None and loss.dim() == 0 and loss.dtype == self._unit.dtype) else None)
         if self.metrics is not None:
             self.metrics.add(pred.detach(), target)      # one kernel, no host sync (localfunctions.py:220-223)
         return loss.detach()
