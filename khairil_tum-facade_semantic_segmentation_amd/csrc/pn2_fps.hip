@@ -11,6 +11,36 @@ int launch_ball_bin(const float *xyz, const float *new_xyz, int B, int N, int S,
 
 namespace {
 
+// The per-iteration arg-max is what this kernel's time is made of (two waves per SIMD, ~170 instructions per iteration
+// before this form): reductions with the DPP operand fused into v_max_i32 (the builtin form costs copy + wait + move + max
+// per step), the last two steps across rows with row_bcast instead of four read-lanes, and the running minimum as one
+// v_min_f32 (`d < md ? d : md` compiles to compare + wait + select; for the values that occur -- d >= 0 or NaN -- the
+// IEEE minimum gives the same bits: a NaN d keeps md).
+__device__ __forceinline__ int fps_row_max(int v)            // max over each 16-lane row, in every lane of the row
+{
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int fps_wave_max(int v)           // max over the 64 lanes, uniform
+{
+    v = fps_row_max(v);
+    asm("v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float fps_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // T threads, P consecutive points per thread (thread t owns points t*P .. t*P+P-1, so lane
 // order == index order and "first lane with the max" == "lowest index with the max", the tie
 // rule of torch.max (:83)).
@@ -69,16 +99,33 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
 
         int best = __float_as_int(-1.0f);
         int bestj = 0;
+        float dk[P];
+        if (P % 2 == 0) {
+            // two points per packed instruction (v_pk_add / v_pk_mul: 8 for a pair instead of 12 scalar ones)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+            for (int k = 0; k + 1 < P; k += 2) {
+                const f2 x = {px[k], px[k + 1]}, y = {py[k], py[k + 1]}, z = {pz[k], pz[k + 1]};
+                const f2 dx = x - c2x, dy = y - c2y, dz = z - c2z;
+                const f2 d = (dx * dx + dy * dy) + dz * dz;                      // :80, un-fused
+                dk[k] = d.x; dk[k + 1] = d.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+                dk[k] = (dx * dx + dy * dy) + dz * dz;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
-            const float d = (dx * dx + dy * dy) + dz * dz;                       // :80, un-fused
-            md[k] = d < md[k] ? d : md[k];                                       // :81-82
+            md[k] = fps_min(dk[k], md[k]);                                       // :81-82 (mask = dist < distance)
             // non-negative floats (and the -1 padding) order like their bit patterns as signed ints
             const int bits = __float_as_int(md[k]);
             if (bits > best) { best = bits; bestj = tid * P + k; }               // strict: lowest k wins
         }
-        const int wmax = pn2::wave_max_i32(best);
+        const int wmax = fps_wave_max(best);
         const unsigned long long m = __ballot(best == wmax);
         const int wl = __builtin_ctzll(m);
         int widx = __builtin_amdgcn_readlane(bestj, wl);
@@ -88,7 +135,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
             __syncthreads();
             const unsigned long long e = s[lane & (W - 1)];
             const int ev = (int)(e >> 32);
-            const int gmax = pn2::wave_max_i32(ev);
+            const int gmax = fps_row_max(ev);                                    // W <= 16 entries repeat in every row
             const unsigned long long gm = __ballot(ev == gmax);
             const int gl = __builtin_ctzll(gm);                                  // lowest wave == lowest index
             widx = __builtin_amdgcn_readlane((int)(unsigned)e, gl);
