@@ -1275,6 +1275,365 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
     }
 }
 
+// Split-role form of mlp_dw_kernel<true, POOLED> (the VEC4 staging, the same tiles, the same slabs): in the form above
+// the four waves of a workgroup stage a tile (loads, dz from g and z, BatchNorm + ReLU of the input: ~800 vector
+// instructions a wave), meet at a barrier, multiply (64 MFMAs a wave), meet again -- the matrix pipe idles while the tile
+// is staged (25-31 % busy).  Here waves 4..11 only stage (tile i+1 into the other LDS buffer; a thread owns four rows of a
+// tile and keeps the loads of TWO later tiles in flight in two register sets, so a load has a whole tile period to land)
+// and waves 0..3 only multiply (tile i), one barrier per tile; 139 KB of LDS, one 12-wave workgroup per CU.  (With four
+// staging waves and one register set the multipliers waited two thirds of the time: rocprofv3 SQ_WAIT_ANY 43 %.)
+constexpr int DWS_THREADS = 768;
+constexpr int DWS_TILE = MLP_BM * DW_LD;                   // floats of one staged operand tile
+constexpr size_t DWS_LDS = (size_t)4 * DWS_TILE * sizeof(float);
+
+template <bool POOLED>
+__global__ __launch_bounds__(DWS_THREADS) void mlp_dw_split_kernel(DwArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float dws_lds[];        // [2 buffers][dz tile | act tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.y * DW_BN, k0 = blockIdx.z * DW_BK;
+    const int Kact = p.K1 + p.K2, Kout = Kact + 1;
+    const int ntiles = (p.M + MLP_BM - 1) / MLP_BM;
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    float *out = p.partial + (size_t)blockIdx.x * p.N * Kout;
+
+    if (wave >= 4) {
+        // ---------------- stagers: thread st owns 4 dz columns and 4 act columns of rows rb, rb + 32, rb + 64, rb + 96
+        const int st = tid - 256;
+        const int c4 = (st & 15) * 4, rb = st >> 4;
+        const int n4 = n0 + c4, k4 = k0 + c4;
+        const bool n_ok = n4 < p.N, k_act = k4 < Kact, from1 = k4 < p.K1;
+        float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, is = sc, a1 = sc, a2 = sc, asc = sc, ash = sc;
+        if (n_ok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n4);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n4);
+            mu = *reinterpret_cast<const float4 *>(p.mean + n4);
+            is = *reinterpret_cast<const float4 *>(p.invstd + n4);
+            a1 = *reinterpret_cast<const float4 *>(p.c1 + n4);
+            a2 = *reinterpret_cast<const float4 *>(p.c2 + n4);
+        }
+        if (k_act && p.ascale) {
+            asc = *reinterpret_cast<const float4 *>(p.ascale + k4);
+            ash = *reinterpret_cast<const float4 *>(p.ashift + k4);
+        }
+        const int n4c = n_ok ? n4 : 0;
+        const float *xsrc = from1 ? p.x1 : (p.x2 ? p.x2 : p.x1);
+        const int xld = from1 ? p.ld1 : (p.x2 ? p.ld2 : p.ld1), xcol = k_act ? (from1 ? k4 : k4 - p.K1) : 0;
+        struct Regs { float4 g[4], z[4], x[4]; uchar4 a[4]; };
+        Regs R0, R1;
+        auto issue = [&](Regs &R, int i) {                     // unconditional loads (clamped rows), masked on use
+            const int row0 = ((int)blockIdx.x + i * (int)gridDim.x) * MLP_BM;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = min(row0 + rb + 32 * u, p.M - 1);
+                if (POOLED) {
+                    const int cent = row / p.pool_k;
+                    R.g[u] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4c);
+                    R.a[u] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4c);
+                } else {
+                    R.g[u] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4c);
+                }
+                R.z[u] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4c);
+                R.x[u] = *reinterpret_cast<const float4 *>(xsrc + (size_t)row * xld + xcol);
+            }
+        };
+        auto commit = [&](const Regs &R, int i) {
+            const int row0 = ((int)blockIdx.x + i * (int)gridDim.x) * MLP_BM;
+            float *sD = dws_lds + (i & 1) * 2 * DWS_TILE, *sX = sD + DWS_TILE;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + 32 * u;
+                const int row = row0 + r;
+                float4 dv = make_float4(0, 0, 0, 0), av4 = make_float4(0, 0, 0, 0);
+                if (row < p.M) {
+                    if (n_ok) {
+                        float4 g = R.g[u];
+                        if (POOLED) {
+                            const int kk = row % p.pool_k;
+                            g.x = R.a[u].x == kk ? g.x : 0.f;
+                            g.y = R.a[u].y == kk ? g.y : 0.f;
+                            g.z = R.a[u].z == kk ? g.z : 0.f;
+                            g.w = R.a[u].w == kk ? g.w : 0.f;
+                        }
+                        const float4 z = R.z[u];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                        PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                        dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
+                    }
+                    if (k_act) {
+                        av4 = R.x[u];
+                        if (p.ascale) {
+                            av4.x = fmaxf(asc.x * av4.x + ash.x, 0.f);
+                            av4.y = fmaxf(asc.y * av4.y + ash.y, 0.f);
+                            av4.z = fmaxf(asc.z * av4.z + ash.z, 0.f);
+                            av4.w = fmaxf(asc.w * av4.w + ash.w, 0.f);
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(&sD[r * DW_LD + c4]) = dv;
+                *reinterpret_cast<float4 *>(&sX[r * DW_LD + c4]) = av4;
+            }
+        };
+        // tile j lives in register set j & 1 from its issue to its commit
+        if (my_tiles > 0) issue(R0, 0);
+        if (my_tiles > 1) issue(R1, 1);
+        if (my_tiles > 0) commit(R0, 0);
+        if (my_tiles > 2) issue(R0, 2);
+        __syncthreads();                                          // tile 0 is staged
+        for (int i = 0; i < my_tiles; i += 2) {
+            if (i + 1 < my_tiles) commit(R1, i + 1);              // into the buffer the multipliers left at the last barrier
+            if (i + 3 < my_tiles) issue(R1, i + 3);
+            __syncthreads();
+            if (i + 1 < my_tiles) {
+                if (i + 2 < my_tiles) commit(R0, i + 2);
+                if (i + 4 < my_tiles) issue(R0, i + 4);
+                __syncthreads();
+            }
+        }
+        // bias gradient: 32 stager threads hold partial sums of the same 4 columns; the buffers are free now
+        __syncthreads();                                          // (the multipliers' accumulator images are written)
+        float *cs = dws_lds + 4 * 64 * DW_LD;                     // [32][64] behind the four accumulator images
+        *reinterpret_cast<float4 *>(&cs[rb * 64 + c4]) = dbs;
+        __syncthreads();
+        if (blockIdx.z == 0 && st < 64 && n0 + st < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t += cs[u * 64 + st];
+            out[(size_t)(n0 + st) * Kout + Kact] = t;
+        }
+    } else {
+        // ---------------- multipliers: wave w reduces over rows 32 w .. 32 w + 31 of every tile, all 64 x 64 outputs
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        __syncthreads();
+        for (int i = 0; i < my_tiles; ++i) {
+            const float *sD = dws_lds + (i & 1) * 2 * DWS_TILE, *sX = sD + DWS_TILE;
+            const float *dBase = &sD[(wave * 32 + 16 * half) * DW_LD];
+            const float *xBase = &sX[(wave * 32 + 16 * half) * DW_LD];
+            float a0 = dBase[l31], a1v = dBase[32 + l31], b0 = xBase[l31], b1 = xBase[32 + l31];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float a0n = a0, a1n = a1v, b0n = b0, b1n = b1;
+                if (t + 1 < 16) {
+                    a0n = dBase[(t + 1) * DW_LD + l31]; a1n = dBase[(t + 1) * DW_LD + 32 + l31];
+                    b0n = xBase[(t + 1) * DW_LD + l31]; b1n = xBase[(t + 1) * DW_LD + 32 + l31];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc[1][1], 0, 0, 0);
+                a0 = a0n; a1v = a1n; b0 = b0n; b1 = b1n;
+            }
+            __syncthreads();
+        }
+        // the four waves' accumulators as four images in LDS (the tile buffers are free: everybody passed the last barrier)
+        float *img = dws_lds + wave * 64 * DW_LD;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    img[n * DW_LD + b * 32 + l31] = acc[a][b][r];
+                }
+        __syncthreads();
+        __syncthreads();                                          // (the stagers' column sums are written)
+    }
+    // every thread: sum the four images in wave order (the order of the one-role form) and store the slab block
+    for (int e = tid; e < 64 * 64; e += DWS_THREADS) {
+        const int n = e >> 6, k = e & 63;
+        if (n0 + n < p.N && k0 + k < Kact) {
+            const float *q = dws_lds + n * DW_LD + k;
+            float v = q[0];
+            v += q[64 * DW_LD]; v += q[2 * 64 * DW_LD]; v += q[3 * 64 * DW_LD];
+            pn2::store_rows(&out[(size_t)(n0 + n) * Kout + k0 + k], v);
+        }
+    }
+}
+
+// The same roles on 128 (n) x 128 (k) output blocks and 64-row tiles (N, K >= 128): a staged byte feeds twice the MFMAs
+// of the 64 x 64 form -- that form needs 98 KB per CU every 1.7 us to keep the matrix pipe busy (14.7 TB/s over the chip;
+// it gets ~3.5 out of L2 / MALL, which is what its 25-31 % busy fraction is).  Multiplier wave (wn, wk) owns one 64 x 64
+// quadrant over all 64 rows of a tile (128 MFMAs a tile, no cross-wave sum at the end); the eight staging waves stage
+// 64 rows x (128 dz + 128 act) columns: the same bytes per tile as above in twice the time.
+// Measured with the roles switched off one at a time (fp2's first layer, M = 16384, 256 x 384, 47.5 us): neither role
+// 13.9 us (launch, first tile, 16.5 MB of slabs), staging alone 23.7, multiplying alone 48.4 -- this form IS bound by its
+// MFMAs, at 92 clocks of 2.4 GHz each instead of 64: in an MFMA-dense loop on random data the chip holds ~1.6 GHz
+// (MI355X_MICROARCH.md, "DVFS give-back"), so the fp32 matrix peak such a loop can reach is ~105 TFLOP/s, not 157.
+constexpr int DWW_ROWS = 64, DWW_LD = 132;
+constexpr int DWW_TILE = DWW_ROWS * DWW_LD;
+constexpr size_t DWW_LDS = (size_t)4 * DWW_TILE * sizeof(float);
+
+template <bool POOLED>
+__global__ __launch_bounds__(DWS_THREADS) void mlp_dw_split128_kernel(DwArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float dws_lds[];        // [2 buffers][dz tile | act tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+    const int Kact = p.K1 + p.K2, Kout = Kact + 1;
+    const int ntiles = (p.M + DWW_ROWS - 1) / DWW_ROWS;
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    float *out = p.partial + (size_t)blockIdx.x * p.N * Kout;
+
+    if (wave >= 4) {
+        // ---------------- stagers: thread st owns 4 dz columns and 4 act columns of rows rb, rb + 16, rb + 32, rb + 48
+        const int st = tid - 256;
+        const int c4 = (st & 31) * 4, rb = st >> 5;
+        const int n4 = n0 + c4, k4 = k0 + c4;
+        const bool n_ok = n4 < p.N, k_act = k4 < Kact, from1 = k4 < p.K1;
+        float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, is = sc, a1 = sc, a2 = sc, asc = sc, ash = sc;
+        if (n_ok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n4);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n4);
+            mu = *reinterpret_cast<const float4 *>(p.mean + n4);
+            is = *reinterpret_cast<const float4 *>(p.invstd + n4);
+            a1 = *reinterpret_cast<const float4 *>(p.c1 + n4);
+            a2 = *reinterpret_cast<const float4 *>(p.c2 + n4);
+        }
+        if (k_act && p.ascale) {
+            asc = *reinterpret_cast<const float4 *>(p.ascale + k4);
+            ash = *reinterpret_cast<const float4 *>(p.ashift + k4);
+        }
+        const int n4c = n_ok ? n4 : 0;
+        const float *xsrc = from1 ? p.x1 : (p.x2 ? p.x2 : p.x1);
+        const int xld = from1 ? p.ld1 : (p.x2 ? p.ld2 : p.ld1), xcol = k_act ? (from1 ? k4 : k4 - p.K1) : 0;
+        struct Regs { float4 g[4], z[4], x[4]; uchar4 a[4]; };
+        Regs R0, R1;
+        auto issue = [&](Regs &R, int i) {
+            const int row0 = ((int)blockIdx.x + i * (int)gridDim.x) * DWW_ROWS;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = min(row0 + rb + 16 * u, p.M - 1);
+                if (POOLED) {
+                    const int cent = row / p.pool_k;
+                    R.g[u] = *reinterpret_cast<const float4 *>(p.g + (size_t)cent * p.ldg + n4c);
+                    R.a[u] = *reinterpret_cast<const uchar4 *>(p.argk + (size_t)cent * p.N + n4c);
+                } else {
+                    R.g[u] = *reinterpret_cast<const float4 *>(p.g + (size_t)row * p.ldg + n4c);
+                }
+                R.z[u] = *reinterpret_cast<const float4 *>(p.z + (size_t)row * p.ldz + n4c);
+                R.x[u] = *reinterpret_cast<const float4 *>(xsrc + (size_t)row * xld + xcol);
+            }
+        };
+        auto commit = [&](const Regs &R, int i) {
+            const int row0 = ((int)blockIdx.x + i * (int)gridDim.x) * DWW_ROWS;
+            float *sD = dws_lds + (i & 1) * 2 * DWW_TILE, *sX = sD + DWW_TILE;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + 16 * u;
+                const int row = row0 + r;
+                float4 dv = make_float4(0, 0, 0, 0), av4 = make_float4(0, 0, 0, 0);
+                if (row < p.M) {
+                    if (n_ok) {
+                        float4 g = R.g[u];
+                        if (POOLED) {
+                            const int kk = row % p.pool_k;
+                            g.x = R.a[u].x == kk ? g.x : 0.f;
+                            g.y = R.a[u].y == kk ? g.y : 0.f;
+                            g.z = R.a[u].z == kk ? g.z : 0.f;
+                            g.w = R.a[u].w == kk ? g.w : 0.f;
+                        }
+                        const float4 z = R.z[u];
+#define PN2_DZ(f) dv.f = sc.f * (((sc.f * z.f + sh.f) > 0.f ? g.f : 0.f) - a1.f - (z.f - mu.f) * is.f * a2.f)
+                        PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+                        dbs.x += dv.x; dbs.y += dv.y; dbs.z += dv.z; dbs.w += dv.w;
+                    }
+                    if (k_act) {
+                        av4 = R.x[u];
+                        if (p.ascale) {
+                            av4.x = fmaxf(asc.x * av4.x + ash.x, 0.f);
+                            av4.y = fmaxf(asc.y * av4.y + ash.y, 0.f);
+                            av4.z = fmaxf(asc.z * av4.z + ash.z, 0.f);
+                            av4.w = fmaxf(asc.w * av4.w + ash.w, 0.f);
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(&sD[r * DWW_LD + c4]) = dv;
+                *reinterpret_cast<float4 *>(&sX[r * DWW_LD + c4]) = av4;
+            }
+        };
+        if (my_tiles > 0) issue(R0, 0);
+        if (my_tiles > 1) issue(R1, 1);
+        if (my_tiles > 0) commit(R0, 0);
+        if (my_tiles > 2) issue(R0, 2);
+        __syncthreads();                                          // tile 0 is staged
+        for (int i = 0; i < my_tiles; i += 2) {
+            if (i + 1 < my_tiles) commit(R1, i + 1);
+            if (i + 3 < my_tiles) issue(R1, i + 3);
+            __syncthreads();
+            if (i + 1 < my_tiles) {
+                if (i + 2 < my_tiles) commit(R0, i + 2);
+                if (i + 4 < my_tiles) issue(R0, i + 4);
+                __syncthreads();
+            }
+        }
+        // bias gradient: 16 stager threads hold partial sums of the same 4 columns; the tile buffers are free now
+        float *cs = dws_lds;                                      // [16][128]
+        *reinterpret_cast<float4 *>(&cs[rb * 128 + c4]) = dbs;
+        __syncthreads();
+        if (blockIdx.z == 0 && st < 128 && n0 + st < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += cs[u * 128 + st];
+            out[(size_t)(n0 + st) * Kout + Kact] = t;
+        }
+    } else {
+        // ---------------- multipliers: wave (wn, wk) owns the 64 x 64 quadrant at (64 wn, 64 wk) over all rows
+        const int wn = wave & 1, wk = wave >> 1;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        __syncthreads();
+        for (int i = 0; i < my_tiles; ++i) {
+            const float *sD = dws_lds + (i & 1) * 2 * DWW_TILE, *sX = sD + DWW_TILE;
+            const float *dBase = &sD[(32 * half) * DWW_LD + wn * 64 + l31];      // lane half h: rows 32 h .. 32 h + 31
+            const float *xBase = &sX[(32 * half) * DWW_LD + wk * 64 + l31];
+            float a0 = dBase[0], a1v = dBase[32], b0 = xBase[0], b1 = xBase[32];
+#pragma unroll 8
+            for (int t = 0; t < 32; ++t) {
+                float a0n = a0, a1n = a1v, b0n = b0, b1n = b1;
+                if (t + 1 < 32) {
+                    a0n = dBase[(t + 1) * DWW_LD]; a1n = dBase[(t + 1) * DWW_LD + 32];
+                    b0n = xBase[(t + 1) * DWW_LD]; b1n = xBase[(t + 1) * DWW_LD + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc[1][1], 0, 0, 0);
+                a0 = a0n; a1v = a1n; b0 = b0n; b1 = b1n;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int k = k0 + wk * 64 + b * 32 + l31;
+                    if (n < p.N && k < Kact) pn2::store_rows(&out[(size_t)n * Kout + k], acc[a][b][r]);
+                }
+        __syncthreads();                                          // (the stagers' column sums)
+    }
+}
+
 // Wide-layer form of mlp_dw_kernel (N >= 128 and K >= 128, all-float4): a workgroup owns a
 // 128(n) x 128(k) block of dW, each wave a 64 x 64 quarter of it over ALL rows of every 64-row
 // tile (no cross-wave reduction), so a staged element feeds twice as many MFMAs and the dz / act
@@ -1927,13 +2286,30 @@ PN2_EXPORT int pn2_bn_relu_out(const float *z, long long rows_out, int C, int po
     return PN2_LAUNCH_RC();
 }
 
+// 128 x 128 output blocks pay when little of the last k block is padding (sa4's 260 inputs would pad to 384)
+static bool dw_split128_applies(int N, int K)
+{
+    if (N < 128 || K < 128 || !pn2::tune_get("mlp_dw_split", 1) || !pn2::tune_get("mlp_dw_split128", 1)) return false;
+    const int kp = (K + 127) / 128 * 128, np = (N + 127) / 128 * 128;
+    return (long long)kp * np * 4 <= (long long)K * N * 5;             // at most 25 % more products than the layer has
+}
+
 PN2_EXPORT int pn2_mlp_dw_partials(int M, int N, int K)
 {
     // ~512 workgroups in flight (2 per CU): the M axis is split so that (M slabs) x (64x64 output blocks) ~ 512
+    if (dw_split128_applies(N, K)) {
+        // one 12-wave workgroup per CU: (M slabs) x (128 x 128 output blocks) ~ 256, 64-row tiles
+        const int nt = (M + DWW_ROWS - 1) / DWW_ROWS;
+        int q = pn2::tune_get("dw_split_wgs", 256) / (((N + 127) / 128) * ((K + 127) / 128));
+        q = q < 8 ? 8 : q;
+        return q > nt ? nt : q;
+    }
     const bool wide = N >= 128 && K >= 128 && pn2::tune_get("mlp_dw128", 0);
     const int ntiles = wide ? (M + DW2_ROWS - 1) / DW2_ROWS : (M + MLP_BM - 1) / MLP_BM;
     const int blocks = wide ? ((N + 127) / 128) * ((K + 127) / 128) : ((N + DW_BN - 1) / DW_BN) * ((K + DW_BK - 1) / DW_BK);
-    int p = pn2::tune_get("dw_wgs", 512) / (blocks < 1 ? 1 : blocks);      // 256/384/640/1024 measured slower
+    // the split-role form holds one 8-wave workgroup per CU
+    const int wgs = (!wide && pn2::tune_get("mlp_dw_split", 1)) ? pn2::tune_get("dw_split_wgs", 256) : pn2::tune_get("dw_wgs", 512);
+    int p = wgs / (blocks < 1 ? 1 : blocks);                                // one-role form: 256/384/640/1024 measured slower
     // (a cap tying the partial-slab traffic to the layer's input traffic was measured: no gain)
     const int div = pn2::tune_get("dw_p_div", 0);
     if (div > 0) {
@@ -2038,6 +2414,27 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
         grid.z = (unsigned)((K + 127) / 128);
         if (argk) hipLaunchKernelGGL(mlp_dw128_kernel<true>, grid, dim3(MLP_THREADS), 0, stream, a);
         else hipLaunchKernelGGL(mlp_dw128_kernel<false>, grid, dim3(MLP_THREADS), 0, stream, a);
+    } else if (vec4 && dw_split128_applies(N, K)) {
+        grid.y = (unsigned)((N + 127) / 128);
+        grid.z = (unsigned)((K + 127) / 128);
+        static pn2::PerDevice memo_p, memo_d;
+        if (argk) {
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_dw_split128_kernel<true>), (int)DWW_LDS, memo_p)) return e;
+            hipLaunchKernelGGL(mlp_dw_split128_kernel<true>, grid, dim3(DWS_THREADS), DWW_LDS, stream, a);
+        } else {
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_dw_split128_kernel<false>), (int)DWW_LDS, memo_d)) return e;
+            hipLaunchKernelGGL(mlp_dw_split128_kernel<false>, grid, dim3(DWS_THREADS), DWW_LDS, stream, a);
+        }
+    } else if (vec4 && pn2::tune_get("mlp_dw_split", 1)) {
+        grid.z = (unsigned)((K + DW_BK - 1) / DW_BK);             // the bias column is summed on the side
+        static pn2::PerDevice memo_p, memo_d;
+        if (argk) {
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_dw_split_kernel<true>), (int)DWS_LDS, memo_p)) return e;
+            hipLaunchKernelGGL(mlp_dw_split_kernel<true>, grid, dim3(DWS_THREADS), DWS_LDS, stream, a);
+        } else {
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_dw_split_kernel<false>), (int)DWS_LDS, memo_d)) return e;
+            hipLaunchKernelGGL(mlp_dw_split_kernel<false>, grid, dim3(DWS_THREADS), DWS_LDS, stream, a);
+        }
     } else if (vec4) {
         grid.z = (unsigned)((K + DW_BK - 1) / DW_BK);             // the bias column is summed on the side
         if (argk) hipLaunchKernelGGL((mlp_dw_kernel<true, true>), grid, dim3(MLP_THREADS), 0, stream, a);
