@@ -796,6 +796,112 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Very-few-rows form (fp4: M <= 1024 rows against K, N of 256 ... 768): a 32 x 128 tile per workgroup leaves three
+// quarters of the chip idle and runs its K loop as 12 ... 24 dependent load -> multiply steps (25 us for 0.4 GFLOP).  Here a
+// workgroup owns ONE 32 x 32 output block and its eight waves split K: a wave issues every load of its K slice at once,
+// straight into the MFMA operand layout (lane (i = l & 31, h = l >> 5) holds four consecutive k of row i / column i: the
+// four k of lane half 0 and the four of half 1 feed four MFMAs, any pairing of k values is a valid contraction), multiplies
+// as the loads land, and wave 0 sums the eight partial accumulators in wave order and runs the shared epilogue (bias,
+// ReLU mask of the layer below, statistics, stores).  No LDS staging: every operand element is used by exactly one MFMA
+// lane, the re-reads across workgroups (A by N/32 of them, W by M/32) come from L2.
+// Measured (tools/mlpbench.py): fp4 (1024 rows) forward 43.0 -> 24.9 us, forward + backward 116 -> 97 us; fp3 (4096 rows:
+// 1024 workgroups, every operand re-read 8 ... 128 times from L2) 36.9 -> 45.8 and 134 -> 159 us: M <= 1024 only.
+// NS = 8-wide k steps per wave (K <= 64 NS).  Prologues keep their per-k constants in registers beside the operands:
+// PRO_BN_RELU up to NS = 8, PRO_BN_BWD (dz from g and z; explicit g only) at NS = 4.
+template <int PRO, bool WT, int NS>
+__global__ __launch_bounds__(512) void mlp_gemm_tiny_kernel(GemmArgs p)
+{
+    __shared__ float sAcc[7][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+    const int row = row0 + l31, col = col0 + l31;
+    const int rowc = min(row, p.M - 1), colc = min(col, p.N - 1);
+    const bool row_ok = row < p.M, col_ok = col < p.N;
+    const int kb = wave * (NS * 8) + 4 * half;               // this lane's first k
+    float4 a[NS], b[NS], z[PRO == PRO_BN_BWD ? NS : 1], cs[PRO != PRO_NONE ? NS : 1], ch[PRO != PRO_NONE ? NS : 1];
+    float4 cm[PRO == PRO_BN_BWD ? NS : 1], ci[PRO == PRO_BN_BWD ? NS : 1], cc1[PRO == PRO_BN_BWD ? NS : 1],
+        cc2[PRO == PRO_BN_BWD ? NS : 1];
+    // ---- every load of the slice (clamped addresses: a k past the end is masked when consumed)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = kb + 8 * s;
+        const int kc = min(k, p.K - 4);
+        if (PRO == PRO_BN_BWD) {
+            a[s] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)rowc * p.ld1 + kc);
+            z[s] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)rowc * p.ld2 + kc);
+        } else {
+            a[s] = kc < p.K1 ? *reinterpret_cast<const float4 *>(p.x1 + (size_t)rowc * p.ld1 + kc)
+                             : *reinterpret_cast<const float4 *>(p.x2 + (size_t)rowc * p.ld2 + (kc - p.K1));
+        }
+        if (!WT) {
+            b[s] = *reinterpret_cast<const float4 *>(p.w + (size_t)colc * p.ldw + kc);
+        } else {
+            const float *wp = p.w + (size_t)kc * p.ldw + colc;
+            b[s] = make_float4(wp[0], wp[p.ldw], wp[2 * (size_t)p.ldw], wp[3 * (size_t)p.ldw]);
+        }
+        if (PRO != PRO_NONE) {
+            cs[s] = *reinterpret_cast<const float4 *>(p.scale + kc);
+            ch[s] = *reinterpret_cast<const float4 *>(p.shift + kc);
+        }
+        if (PRO == PRO_BN_BWD) {
+            cm[s] = *reinterpret_cast<const float4 *>(p.mean + kc);
+            ci[s] = *reinterpret_cast<const float4 *>(p.invstd + kc);
+            cc1[s] = *reinterpret_cast<const float4 *>(p.c1 + kc);
+            cc2[s] = *reinterpret_cast<const float4 *>(p.c2 + kc);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);       // all of them in flight before the first is waited for (left alone, the
+                                             // scheduler sinks each load to its use and the slice runs step by step)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // ---- multiply in the order the loads were issued
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool k_ok = kb + 8 * s < p.K;
+        float4 av = a[s];
+        if (PRO == PRO_BN_RELU) {
+            av.x = fmaxf(cs[s].x * av.x + ch[s].x, 0.f);
+            av.y = fmaxf(cs[s].y * av.y + ch[s].y, 0.f);
+            av.z = fmaxf(cs[s].z * av.z + ch[s].z, 0.f);
+            av.w = fmaxf(cs[s].w * av.w + ch[s].w, 0.f);
+        } else if (PRO == PRO_BN_BWD) {
+            const float4 g = a[s], zz = z[s];
+#define PN2_DZ(f) av.f = cs[s].f * (((cs[s].f * zz.f + ch[s].f) > 0.f ? g.f : 0.f) - cc1[s].f - (zz.f - cm[s].f) * ci[s].f * cc2[s].f)
+            PN2_DZ(x); PN2_DZ(y); PN2_DZ(z); PN2_DZ(w);
+#undef PN2_DZ
+        }
+        if (!(k_ok && row_ok)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bv = b[s];
+        if (!(k_ok && col_ok)) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    // ---- the eight K slices, summed in wave order by wave 0
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sAcc[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 7; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sAcc[w][r][lane];
+    float csum = 0.f, csq = 0.f;
+    if (col_ok) gemm_store_block_any<PRO == PRO_BN_BWD>(p, acc, row0, half, col, p.mask_z != nullptr, csum, csq);
+    if (!p.stat_partial) return;
+    const float ssum = csum + __shfl_xor(csum, 32);
+    const float sq = csq + __shfl_xor(csq, 32);
+    if (half == 0 && col_ok) {
+        p.stat_partial[((size_t)blockIdx.x * 2 + 0) * p.N + col] = ssum;
+        p.stat_partial[((size_t)blockIdx.x * 2 + 1) * p.N + col] = sq;
+    }
+}
+
 // Fixed-order partial sums with all loads issued before the first add: thread slice py takes partials py,
 // py+32, ... (even ones into s0, odd ones into s1).  NJ = compile-time bound on the number per thread.
 template <int NJ>
@@ -2115,6 +2221,27 @@ static int mlp_gemm_impl(const float *x1, int ld1, int K1, const float *x2, int 
     {
         bool pipe_ok = vec4 && (ldw % 4 == 0) && aligned16(w) && (w_is_kn ? (N % 4 == 0) : true);
         if (prologue == PRO_BN_BWD && argk) pipe_ok = pipe_ok && ((reinterpret_cast<uintptr_t>(argk) & 3) == 0);
+        // very few rows: one 32 x 32 block per workgroup, K split over its eight waves (statistics: one partial row per
+        // 32-row tile = pn2_mlp_gemm_max_partials(M) of them)
+        // (the pooled epilogue is the shared one: a 32-row block is a group, so pooled and plain layers keep the same sums)
+        if (pipe_ok && !(pool_max && M % 32) && !a.argk && M <= pn2::tune_get("mlp_tiny_rows", 1024) && (M + 31) / 32 == gx) {
+            const int ns = (a.K + 63) / 64;                        // 8-wide steps per wave
+            dim3 grid((unsigned)gx, (unsigned)((N + 31) / 32));
+            hipStream_t st = stream;
+#define PN2_TINY(P, W, NS) do { hipLaunchKernelGGL((mlp_gemm_tiny_kernel<P, W, NS>), grid, dim3(512), 0, st, a); return PN2_LAUNCH_RC(); } while (0)
+            if (prologue == PRO_NONE && !a.wt) {
+                if (ns <= 4) PN2_TINY(PRO_NONE, false, 4);
+                if (ns <= 8) PN2_TINY(PRO_NONE, false, 8);
+                if (ns <= 12) PN2_TINY(PRO_NONE, false, 12);
+                if (ns <= 16) PN2_TINY(PRO_NONE, false, 16);
+            } else if (prologue == PRO_BN_RELU && !a.wt) {
+                if (ns <= 4) PN2_TINY(PRO_BN_RELU, false, 4);
+                if (ns <= 8) PN2_TINY(PRO_BN_RELU, false, 8);
+            } else if (prologue == PRO_BN_BWD && a.wt && (N % 4 == 0)) {
+                if (ns <= 4) PN2_TINY(PRO_BN_BWD, true, 4);
+            }
+#undef PN2_TINY
+        }
         // few rows: 32-row tiles so that (row tiles) x (128-column blocks) still covers the 256 CUs
         if (pipe_ok && pn2_mlp_gemm_uses_rows32(M, N) && pn2::tune_get("mlp_rows32", 1)) {
             int pool_shift = -1;
