@@ -59,6 +59,9 @@ CASES = [
     (2500, 64, 0, (256, 128), 0),                # ... 256 inputs with the statistics of the layer below
     (66017, 16, 0, (32, 64), 0),                 # 128-row pipelined tiles, last tile / last 32-row block ragged
     (16408, 128, 0, (256, 256), 0),              # 64-row tiles (64-wide K steps in the dX GEMM), ragged
+    (1000, 512, 256, (256, 136), 0),             # FP4 shape: very-few-rows GEMM, K = 768 over eight waves, ragged rows / columns
+    (333, 1024, 0, (72, 256), 0),                # ... 16 steps per wave; dX through the k-major weight; N not a multiple of 32
+    (1024, 64, 0, (64, 128), 32),                # ... with the pooled epilogue
 ]
 
 
