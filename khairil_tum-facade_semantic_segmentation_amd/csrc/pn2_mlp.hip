@@ -1572,9 +1572,13 @@ __global__ __launch_bounds__(DWS_THREADS) void mlp_dw_split_kernel(DwArgs p)
 // quadrant over all 64 rows of a tile (128 MFMAs a tile, no cross-wave sum at the end); the eight staging waves stage
 // 64 rows x (128 dz + 128 act) columns: the same bytes per tile as above in twice the time.
 // Measured with the roles switched off one at a time (fp2's first layer, M = 16384, 256 x 384, 47.5 us): neither role
-// 13.9 us (launch, first tile, 16.5 MB of slabs), staging alone 23.7, multiplying alone 48.4 -- this form IS bound by its
-// MFMAs, at 92 clocks of 2.4 GHz each instead of 64: in an MFMA-dense loop on random data the chip holds ~1.6 GHz
-// (MI355X_MICROARCH.md, "DVFS give-back"), so the fp32 matrix peak such a loop can reach is ~105 TFLOP/s, not 157.
+// 13.9 us (launch, first tile, 16.5 MB of slabs), staging alone 23.7, multiplying alone 48.4: whole = fixed + max of the
+// two, the stagers' vector instructions fit into the gaps of this multiplier loop (an MFMA every ~103 clocks: a wave can
+// issue nothing else while its MFMA holds the issue slot, and four ds_read_b32 + moves per four MFMAs cost ~40 clocks
+// apiece).  A loop with one ds_read_b128 + one ds_read_b64 per EIGHT MFMAs multiplies alone in 38.3 us -- and the whole
+// kernel still takes 47.5: with the matrix pipe saturated the staging no longer overlaps, the times ADD (fixed 15.0 +
+// staging 9.7 + multiplying 23.3).  The clock stays at 2.39 GHz throughout (tools/bqlab/lab6.hip).  The simple loop
+// stays (profiles/r03/dw_split128_roles_switched_off.log, dw_split128_wide_operand_reads_withdrawn.patch).
 constexpr int DWW_ROWS = 64, DWW_LD = 132;
 constexpr int DWW_TILE = DWW_ROWS * DWW_LD;
 constexpr size_t DWW_LDS = (size_t)4 * DWW_TILE * sizeof(float);
