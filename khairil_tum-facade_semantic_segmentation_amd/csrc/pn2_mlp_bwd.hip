@@ -674,8 +674,14 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
     } else {
         // ================================ multipliers ================================================
         // dX block b = rb*KBLK + cb on wave b % NMW (slot b / NMW); dW blocks: see DWHI / DWLO
+        // SHARED (the 128 x 128 form: four waves without a dX block, four dW blocks each): a wave takes ONE block of input
+        // columns (kb) and all NBLK blocks of dz columns, so the activated input operand is read and activated once per
+        // row and shared by its four MFMAs (before: one dz block per wave, the input re-read and re-activated per block
+        // and by all four waves -- every vector instruction of a multiplier adds to the SIMD's time)
+        constexpr bool SHARED = NUP > 0 && NUP == KBLK && DWHI == NBLK && DWLO == 0;
         auto dw_block = [&](int i) -> int {
             if (NUP == 0) { const int b = (NMW - 1 - wave) + NMW * i; return b < NDW ? b : -1; }
+            if (SHARED) return (wave >= NDX && i < NBLK) ? i * KBLK + (wave - NDX) : -1;
             if (wave >= NDX) return i < DWHI ? (wave - NDX) * DWHI + i : -1;
             const int b = NUP * DWHI + wave * DWLO + i;
             return (i < DWLO && b < NDW) ? b : -1;
@@ -759,6 +765,34 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
                     }
                 }
             }
+            if (SHARED) {
+                if (wave >= NDX) {
+                    constexpr int HR = TR / 2;                       // rows per lane half
+                    const float *dBase = &sD[(HR * half) * LDD + l31];
+                    const float *xBase = &sZ[(HR * half) * LDZ + (wave - NDX) * 32 + l31];
+                    float xr = xBase[0], a[DWPW];
+#pragma unroll
+                    for (int i = 0; i < DWPW; ++i) a[i] = dBase[i * 32];
+#pragma unroll
+                    for (int t = 0; t < HR; ++t) {
+                        float xn = xr, an[DWPW];
+#pragma unroll
+                        for (int i = 0; i < DWPW; ++i) an[i] = a[i];
+                        if (t + 1 < HR) {
+                            xn = xBase[(t + 1) * LDZ];
+#pragma unroll
+                            for (int i = 0; i < DWPW; ++i) an[i] = dBase[(t + 1) * LDD + i * 32];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float xv2 = masked ? fmaxf(wsc[0] * xr + wsh[0], 0.f) : xr;
+#pragma unroll
+                        for (int i = 0; i < DWPW; ++i) accW[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], xv2, accW[i], 0, 0, 0);
+                        xr = xn;
+#pragma unroll
+                        for (int i = 0; i < DWPW; ++i) a[i] = an[i];
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < DWPW; ++i) {
                 const int b = dw_block(i);
