@@ -287,6 +287,10 @@ int pn2_invert_index(const int64_t *idx, int B, long long E, int Nkeys, int32_t 
 int pn2_gather_sum(const float *src, long long rows_src, int lds, int col0, const int32_t *offsets,
                    const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
                    float *out, pn2_stream_t stream);
+/* ... + addend[b][key][c] (nullable): the other gradient of the same rows (a skip connection's) joins the sum. */
+int pn2_gather_sum_add(const float *src, long long rows_src, int lds, int col0, const int32_t *offsets,
+                       const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
+                       const float *addend, float *out, pn2_stream_t stream);
 
 /* ---- segmentation head tail and loss (caller of the hot path) ------------------------
  * x = conv2(x); x = F.log_softmax(x, dim=1)                   models/pointnet2_sem_seg.py:37-38

@@ -90,52 +90,75 @@ __global__ __launch_bounds__(INV_THREADS) void invert_index_kernel(const int64_t
     for (int e = tid; e < E; e += INV_THREADS) be[e] = e < total ? list[e] : -1;
 }
 
-// out[b][key][c] = sum over the key's entries e (ascending) of w[b][e] * src[b][e / ediv][col0 + c].
-// LPR lanes per (b, key) row (a lane owns 4 consecutive columns per pass of 4*LPR columns), 64/LPR rows
-// per wave, 4 entries in flight.
-template <int LPR>
+// out[b][key][c] = addend[b][key][c] + sum over the key's entries e of w[b][e] * src[b][e / ediv][col0 + c].
+// LPR lanes per (b, key) row (a lane owns 4 consecutive columns per pass of 4*LPR columns) times SL slices: slice s sums the
+// entries a + s, a + s + SL, ... (ascending, four in flight), the slices are combined in order s = 0, 1, ... -- a fixed
+// summation order whatever the launch.  The per-key lists have a heavy tail (grouping: 8 entries on average, up to ~100:
+// a point of a dense region sits in many balls); with one lane group walking a whole list, a wave waits for its longest
+// list (the form with SL = 1: 88 us for the three grouping levels against 71 us of float atomics).  64 / (LPR SL) rows per wave.
+template <int LPR, int SL>
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict__ src, long long rows_src, int lds, int col0,
                                                          const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
                                                          const float *__restrict__ weight, long long E, int ediv, int B, int Nkeys,
-                                                         int D, float *__restrict__ out)
+                                                         int D, const float *__restrict__ addend, float *__restrict__ out)
 {
-    constexpr int RPB = 256 / LPR;                                 // rows per workgroup
-    const int sub = threadIdx.x % LPR;
-    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
-    if (row >= (long long)B * Nkeys) return;
+    constexpr int LPK = LPR * SL;                                  // lanes per key row
+    constexpr int RPB = 256 / LPK;                                 // rows per workgroup
+    static_assert(LPK <= 64, "a key row stays inside one wave");
+    const int sub = threadIdx.x % LPR, sl = (threadIdx.x / LPR) % SL;
+    long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPK;
+    const bool live = row < (long long)B * Nkeys;
+    if (!live) row = (long long)B * Nkeys - 1;                    // (the shuffles below need every lane of the wave)
     const int b = (int)(row / Nkeys), key = (int)(row - (long long)b * Nkeys);
     const int32_t *bo = offsets + (size_t)b * (Nkeys + 1);
     const int a = bo[key], z = bo[key + 1];
     const int32_t *be = entries + (size_t)b * E;
     const float *bw = weight ? weight + (size_t)b * E : nullptr;
     const float *bs = src + (size_t)b * rows_src * lds + col0;
-    float *orow = out + (size_t)row * D;
-    for (int c = sub * 4; c < D; c += 4 * LPR) {
+    for (int c0 = 0; c0 < D; c0 += 4 * LPR) {
+        const int c = c0 + sub * 4;
+        const bool col_ok = c < D;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int i = a;
-        for (; i + 4 <= z; i += 4) {
-            int e[4];
-            float w[4];
-            float4 v[4];
+        if (col_ok) {
+            int i = a + sl;
+            for (; i + 3 * SL < z; i += 4 * SL) {
+                int e[4];
+                float w[4];
+                float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                e[u] = be[i + u];
-                w[u] = bw ? bw[e[u]] : 1.0f;
-                const f32x4u t = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e[u] / ediv) * lds + c);
-                v[u] = make_float4(t.x, t.y, t.z, t.w);
+                for (int u = 0; u < 4; ++u) {
+                    e[u] = be[i + u * SL];
+                    w[u] = bw ? bw[e[u]] : 1.0f;
+                    const f32x4u t = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e[u] / ediv) * lds + c);
+                    v[u] = make_float4(t.x, t.y, t.z, t.w);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w;
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w;
+            for (; i < z; i += SL) {
+                const int e = be[i];
+                const float w = bw ? bw[e] : 1.0f;
+                const f32x4u v = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e / ediv) * lds + c);
+                acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
             }
         }
-        for (; i < z; ++i) {
-            const int e = be[i];
-            const float w = bw ? bw[e] : 1.0f;
-            const f32x4u v = *reinterpret_cast<const f32x4u *>(bs + (size_t)(e / ediv) * lds + c);
-            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        if (SL > 1) {                                              // slice 0 collects the others in order
+#pragma unroll
+            for (int s2 = 1; s2 < SL; ++s2) {
+                const float ox = __shfl_down(acc.x, LPR * s2, 64), oy = __shfl_down(acc.y, LPR * s2, 64);
+                const float oz = __shfl_down(acc.z, LPR * s2, 64), ow = __shfl_down(acc.w, LPR * s2, 64);
+                if (sl == 0) { acc.x += ox; acc.y += oy; acc.z += oz; acc.w += ow; }
+            }
         }
-        pn2::store_rows4(out, (size_t)row * D + c, acc, (size_t)B * Nkeys * D * sizeof(float));
+        if (live && col_ok && sl == 0) {
+            if (addend) {
+                const float4 ad = *reinterpret_cast<const float4 *>(addend + (size_t)row * D + c);
+                acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
+            }
+            pn2::store_rows4(out, (size_t)row * D + c, acc, (size_t)B * Nkeys * D * sizeof(float));
+        }
     }
 }
 
@@ -143,7 +166,8 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void gather_sum_scalar_kernel(const float *__restrict__ src, long long rows_src, int lds, int col0,
                                                                 const int32_t *__restrict__ offsets,
                                                                 const int32_t *__restrict__ entries, const float *__restrict__ weight,
-                                                                long long E, int ediv, int B, int Nkeys, int D, float *__restrict__ out)
+                                                                long long E, int ediv, int B, int Nkeys, int D,
+                                                                const float *__restrict__ addend, float *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(256) void gather_sum_scalar_kernel(const float *__r
             const int e = be[i];
             acc += (bw ? bw[e] : 1.0f) * bs[(size_t)(e / ediv) * lds + c];
         }
-        orow[c] = acc;
+        orow[c] = addend ? acc + addend[(size_t)row * D + c] : acc;
     }
 }
 
@@ -187,25 +211,35 @@ PN2_EXPORT int pn2_gather_sum(const float *src, long long rows_src, int lds, int
                               const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
                               float *out, pn2_stream_t stream_)
 {
+    return pn2_gather_sum_add(src, rows_src, lds, col0, offsets, entries, weight, E, ediv, B, Nkeys, D, nullptr, out, stream_);
+}
+
+PN2_EXPORT int pn2_gather_sum_add(const float *src, long long rows_src, int lds, int col0, const int32_t *offsets,
+                                  const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
+                                  const float *addend, float *out, pn2_stream_t stream_)
+{
     PN2_REQUIRE_PTR(src); PN2_REQUIRE_PTR(offsets); PN2_REQUIRE_PTR(entries); PN2_REQUIRE_PTR(out);
     if (B < 0 || E <= 0 || Nkeys <= 0 || D <= 0 || ediv <= 0 || rows_src <= 0 || col0 < 0 || lds < col0 + D) return PN2_ERR_SHAPE;
     if (B == 0) return PN2_OK;
     const long long rows = (long long)B * Nkeys;
-    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(addend) & 15) == 0);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int lpr = !vec4 ? 0 : (D <= 32 ? 8 : (D <= 64 ? 16 : (D <= 128 ? 32 : 64)));
-    const long long rpb = lpr ? 256 / lpr : 4;
+    // slices per key row: lists of four entries and more on average are split (up to 64 lanes per row)
+    int sl = (lpr && E / Nkeys >= 4 && pn2::tune_get("gather_slices", 1)) ? 64 / lpr : 1;
+    if (sl > 4) sl = 4;
+    const long long rpb = lpr ? 256 / (lpr * sl) : 4;
     const long long blocks = (rows + rpb - 1) / rpb;
     if (blocks > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
-#define PN2_GS(L) hipLaunchKernelGGL(gather_sum_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, \
-                                     offsets, entries, weight, E, ediv, B, Nkeys, D, out)
-    if (lpr == 8) PN2_GS(8);
-    else if (lpr == 16) PN2_GS(16);
-    else if (lpr == 32) PN2_GS(32);
-    else if (lpr == 64) PN2_GS(64);
+#define PN2_GS(L, S) hipLaunchKernelGGL((gather_sum_kernel<L, S>), dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, \
+                                        offsets, entries, weight, E, ediv, B, Nkeys, D, addend, out)
+    if (lpr == 8) { if (sl == 4) PN2_GS(8, 4); else PN2_GS(8, 1); }
+    else if (lpr == 16) { if (sl == 4) PN2_GS(16, 4); else PN2_GS(16, 1); }
+    else if (lpr == 32) { if (sl == 2) PN2_GS(32, 2); else PN2_GS(32, 1); }
+    else if (lpr == 64) PN2_GS(64, 1);
     else
         hipLaunchKernelGGL(gather_sum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, offsets,
-                           entries, weight, E, ediv, B, Nkeys, D, out);
+                           entries, weight, E, ediv, B, Nkeys, D, addend, out);
 #undef PN2_GS
     return PN2_LAUNCH_RC();
 }

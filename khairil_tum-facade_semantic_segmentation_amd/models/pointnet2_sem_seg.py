@@ -71,9 +71,11 @@ class get_model(nn.Module):
             else:
                 new_xyz, idx = sa.geometry(levels[-1])
             out += [new_xyz, idx]
-            # A transposed index for the grouping backward is possible too (ops.group_points(inv=...)), but the
-            # per-point lists have a heavy tail (a point sits in up to ~100 balls) and the gather-sum is then
-            # slower than the scatter-add (measured 88 us against 71 us for levels 2-4): interpolation only.
+            # A transposed index for the grouping backward is possible too (ops.group_points(inv=...): atomic-free, a fixed
+            # summation order).  With a key row's list split over four lane slices the gather-sums themselves beat the
+            # float atomics (levels 2-4: 22 + 18 + 14 us against 37 + 20 + 14), but the three extra pn2_invert_index
+            # launches (one 1024-thread workgroup per block, 50-100 us each) put 0.26 ms more on the geometry branch and
+            # its kernels slow the main branch's: +58 us per step (PN2_INVERT_GROUPING=1, profiles/r03).  Interpolation only.
             pair = ops.invert_index(idx, levels[-1].shape[1]) if (i > 0 and _INVERT_GROUPING and for_backward) else None
             inv += list(pair) if pair is not None else [None, None]
             levels.append(new_xyz)

@@ -307,16 +307,20 @@ def invert_index(idx, nkeys):
     return off, ent
 
 
-def _gather_sum(src, rows_src, col0, inv, weight, ediv, nkeys, D):
+def _gather_sum(src, rows_src, col0, inv, weight, ediv, nkeys, D, addend=None):
     dev = _dev(src)
     lib = _lib.load()
     off, ent = inv
     B, E = ent.shape
     out = torch.empty((B, nkeys, D), dtype=torch.float32, device=dev)
+    if addend is not None:
+        addend = _f32c(addend)
+        if tuple(addend.shape) != (B, nkeys, D):
+            raise ValueError("addend %s, expected %s" % (tuple(addend.shape), (B, nkeys, D)))
     with torch.cuda.device(dev):
-        rc = lib.pn2_gather_sum(_ptr(src), rows_src, src.shape[-1], col0, _ptr(off), _ptr(ent), _ptr(weight), E, ediv, B,
-                                nkeys, D, _ptr(out), _stream(dev))
-    _lib.check(rc, "pn2_gather_sum")
+        rc = lib.pn2_gather_sum_add(_ptr(src), rows_src, src.shape[-1], col0, _ptr(off), _ptr(ent), _ptr(weight), E, ediv, B,
+                                    nkeys, D, _ptr(addend), _ptr(out), _stream(dev))
+    _lib.check(rc, "pn2_gather_sum_add")
     return out
 
 
@@ -333,8 +337,7 @@ def index_points_backward(grad_out, idx, N, D, col0=0, inv=None, into=None, into
     M = idx.numel() // max(B, 1)
     Cg = grad_out.shape[-1]
     if inv is not None:
-        out = _gather_sum(grad_out, M, col0, inv, None, 1, N, D)
-        return out if into is None else out + into
+        return _gather_sum(grad_out, M, col0, inv, None, 1, N, D, addend=into)      # the skip gradient joins the sum
     if into is not None and into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == (B, N, D):
         # accumulate on top of the other gradient: a COPY of it (autograd owns `into` -- it may be the same tensor
         # another node receives -- so it is never modified in place; PN2_SKIP_INPLACE=1 restores the in-place form,

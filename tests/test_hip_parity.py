@@ -272,6 +272,10 @@ def test_transposed_index_backward_matches_scatter_add(pn2, orc, B, N, S, K, D):
     assert np.array_equal(grads[0], grads[1])
     want = orc.index_points_backward(host(go)[..., 3:3 + D], idx, N, D)
     np.testing.assert_allclose(grads[0], want, rtol=1e-5, atol=1e-5)
+    # a second gradient of the same points (a skip connection's) joins the gather's sum (pn2_gather_sum_add)
+    other = rs.normal(size=(B, N, D)).astype(np.float32)
+    both = pn2.ops.index_points_backward(go, tidx.reshape(B, -1), N, D, col0=3, inv=inv, into=dev(pn2, other))
+    np.testing.assert_allclose(host(both), want + other, rtol=1e-5, atol=1e-5)
 
     p2 = rs.normal(size=(B, S, D)).astype(np.float32)
     idx3, w3 = pn2.ops.three_nn(dev(pn2, xyz), dev(pn2, new_xyz))
