@@ -23,6 +23,11 @@
 #define PN2_STAMP_DRAIN() do { } while (0)
 #endif
 
+// The kernels of the training step's main branch raise their waves' issue priority: the geometry branch of the same graph
+// (farthest point sampling: two vector-ALU-bound waves per SIMD on 16 CUs for a fifth of the step) shares SIMDs with
+// their workgroups, and a main-branch kernel ends with its slowest workgroup.  The sampling chain has slack.
+#define PN2_MAIN_BRANCH_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
 namespace pn2 {
 // Rows of a tensor the NEXT kernel reads (on any XCD) are written through to memory -- agent-scope atomic stores / sc1
 // buffer stores -- so that they stream out while the kernel computes instead of leaving the launch to end with the

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void index_points_backward_kernel(const float 
                                                                     long long total, int N, int D, long long M,
                                                                     int Cg, int col0, float *__restrict__ grad_points)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
         const long long row = t / D;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void index_points_backward_kernel(const float 
 __global__ __launch_bounds__(256) void copy_pad_cols_kernel(const float *__restrict__ src, int lds, int cols_src,
                                                             float *__restrict__ dst, int ldd, int cols_dst, long long total)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const long long r = t / cols_dst;
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void group_points_flat_kernel(const float *__r
                                                                 unsigned k_magic, unsigned batch_quads,
                                                                 float *__restrict__ grouped, int32_t *err_count)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= batch_quads) return;
     const unsigned b = blockIdx.y;

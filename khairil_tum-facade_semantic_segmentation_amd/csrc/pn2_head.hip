@@ -73,6 +73,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
                                                                 const float *__restrict__ bias,
                                                                 float *__restrict__ logp, int M, int K, int C, DropArgs drop)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
     __shared__ float sL[HD_ROWS][HD_CMAX + 1];
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
                                                                      const float *__restrict__ bias,
                                                                      float *__restrict__ logp, int M, int C, DropArgs drop)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_LDW];
     __shared__ float sL[HD_ROWS][HD_CMAX + 1];
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     const float *__restrict__ g, const float *__restrict__ logp, const float *__restrict__ y, int ldy,
     const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int K, int C, DropArgs drop)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_KMAX];
     __shared__ __attribute__((aligned(16))) float sD[HD_ROWS][HD_CMAX];
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
     const float *__restrict__ g, const float *__restrict__ logp, const float *__restrict__ y, int ldy,
     const float *__restrict__ w, float *__restrict__ gy, int ldgy, float *__restrict__ partial, int M, int C, DropArgs drop)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) float sY[HD_ROWS * HD_LDY];
     __shared__ __attribute__((aligned(16))) float sW[HD_CMAX * HD_LDW];
     __shared__ __attribute__((aligned(16))) float sD[HD_ROWS * HD_LDD];
@@ -442,6 +446,7 @@ __global__ __launch_bounds__(256) void nll_partial_kernel(const float *__restric
                                                          int32_t *__restrict__ err_count, unsigned *__restrict__ ticket,
                                                          float *__restrict__ loss, float *__restrict__ wsum)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ double sN[256], sDn[256];
     __shared__ bool sLast;
     double num = 0.0, den = 0.0;
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(256) void nll_backward_kernel(const float *__restri
                                                           const float *__restrict__ weight, const float *__restrict__ wsum,
                                                           long long M, int C, long long ignore_index, float *__restrict__ glogp)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= M * C) return;
     const long long i = e / C;

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
                                                          const float *__restrict__ weight, long long E, int ediv, int B, int Nkeys,
                                                          int D, const float *__restrict__ addend, float *__restrict__ out)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     constexpr int LPK = LPR * SL;                                  // lanes per key row
     constexpr int RPB = 256 / LPK;                                 // rows per workgroup
     static_assert(LPK <= 64, "a key row stays inside one wave");
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void gather_sum_scalar_kernel(const float *__r
                                                                 long long E, int ediv, int B, int Nkeys, int D,
                                                                 const float *__restrict__ addend, float *__restrict__ out)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)B * Nkeys) return;

@@ -50,6 +50,7 @@ constexpr int MET_MAXC = 64;
 __global__ __launch_bounds__(256) void seg_metrics_kernel(const float *__restrict__ logp, const int64_t *__restrict__ target,
                                                           long long M, int C, unsigned long long *__restrict__ counters)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ unsigned cnt[2 + 3 * MET_MAXC];
     for (int i = threadIdx.x; i < 2 + 3 * C; i += 256) cnt[i] = 0u;
     __syncthreads();

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_gemm_kernel(GemmArgs p)
 template <int BN, int PRO, bool WT, int NW>
 __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel(GemmArgs p, int pool_shift)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     constexpr int T = MLP_THREADS * NW;
     constexpr int NB = BN / 32;
     constexpr int NBW = NB / NW;                      // 32-column blocks per wave
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(MLP_THREADS * NW, 2 * NW) void mlp_gemm_pipe_kernel
 template <int PRO, bool WT, int BM, int BK>
 __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int pool_shift)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     constexpr int BN = 128;
     constexpr int T = 8 * BM;                         // threads
     constexpr int RS = BM / 32;                       // 32-row slices
@@ -812,6 +814,7 @@ __global__ __launch_bounds__(8 * BM) void mlp_gemm_rows32_kernel(GemmArgs p, int
 template <int PRO, bool WT, int NS>
 __global__ __launch_bounds__(512) void mlp_gemm_tiny_kernel(GemmArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ float sAcc[7][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
@@ -1034,6 +1037,7 @@ __device__ __forceinline__ void bn_finalize_block(const BnFinArgs &a, int cb, bo
 // double in a fixed order (deterministic).
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinArgs a)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ float sScale[32], sShift[32];
     bn_finalize_block(a, blockIdx.x, true, sScale, sShift);
 }
@@ -1058,6 +1062,7 @@ struct BnOutArgs {
 
 __global__ __launch_bounds__(1024) void bn_finalize_out_kernel(BnFinArgs a, BnOutArgs o)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ float sScale[32], sShift[32];
     bn_finalize_block(a, blockIdx.x, blockIdx.y == 0, sScale, sShift);
     __syncthreads();
@@ -1185,6 +1190,7 @@ constexpr int DW_BN = 64, DW_BK = 64, DW_LD = 68;
 template <bool VEC4, bool POOLED>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_dw_kernel(DwArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) float sD[MLP_BM * DW_LD];     // dz tile   [128 m][64 n]
     __shared__ __attribute__((aligned(16))) float sX[MLP_BM * DW_LD];     // act tile  [128 m][64 k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -1395,6 +1401,7 @@ constexpr size_t DWS_LDS = (size_t)4 * DWS_TILE * sizeof(float);
 template <bool POOLED>
 __global__ __launch_bounds__(DWS_THREADS) void mlp_dw_split_kernel(DwArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float dws_lds[];        // [2 buffers][dz tile | act tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int n0 = blockIdx.y * DW_BN, k0 = blockIdx.z * DW_BK;
@@ -1586,6 +1593,7 @@ constexpr size_t DWW_LDS = (size_t)4 * DWW_TILE * sizeof(float);
 template <bool POOLED>
 __global__ __launch_bounds__(DWS_THREADS) void mlp_dw_split128_kernel(DwArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float dws_lds[];        // [2 buffers][dz tile | act tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
@@ -1984,6 +1992,7 @@ struct DwReduceMany {
 
 __global__ __launch_bounds__(1024) void dw_reduce_many_kernel(DwReduceMany m)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) float4 sbuf[1024];
     int j = 0;
     while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
@@ -2004,6 +2013,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
                                                             const float *__restrict__ invstd,
                                                             float *__restrict__ partial)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ float sS[8][32], sQ[8][32];
     const int cl = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.y * 32 + cl;
@@ -2037,6 +2047,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec4_kernel(const float *__
                                                                  const float *__restrict__ shift, const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd, float *__restrict__ partial)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ float4 sS[8][32], sQ[8][32];
     const int cl = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c4 = blockIdx.y * 128 + cl * 4;
@@ -2107,6 +2118,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
                                                               float *__restrict__ dbeta, float *__restrict__ c1,
                                                               float *__restrict__ c2)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ double sS[32][33], sQ[32][33];
     bn_bwd_finalize_block(blockIdx.x, partial, P, C, count, dgamma, dbeta, c1, c2, sS, sQ);
 }
@@ -2120,6 +2132,7 @@ __global__ __launch_bounds__(1024) void bwd_post_kernel(const float *__restrict_
                                                        float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                        float *__restrict__ c1, float *__restrict__ c2)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ __attribute__((aligned(16))) double sbuf[2 * 32 * 33];
     static_assert(sizeof(sbuf) >= 1024 * sizeof(float4), "slice combine buffer");
     if ((int)blockIdx.x < nred)

@@ -37,6 +37,7 @@ struct BwdArgs {
 template <int NBLK, int KBLK, bool POOLED>
 __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bwd_fused_kernel(BwdArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     constexpr int NP = 32 * NBLK, KP = 32 * KBLK;
     constexpr int LDD = NP + 4, LDZ = KP + 4;
     constexpr int NDX = 2 * KBLK, NDW = NBLK * KBLK;
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
 template <int NBLK, bool POOLED>
 __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     constexpr int NP = 32 * NBLK, KP = 32;
     constexpr int LDD = NP + 4, LDZ = KP + 4;
     constexpr int ST = 256;                           // staging threads (waves 2..5)
@@ -538,6 +540,7 @@ constexpr int fs_lds_bytes() { return (2 * (FB_ROWS * (32 * NBLK + 4) + FB_ROWS 
 template <int NBLK, int KBLK, bool POOLED, int TR, int NMW, int NSW>
 __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(BwdArgs p)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     constexpr int THREADS = 64 * (NMW + NSW), ST = 64 * NSW;
     constexpr int NP = 32 * NBLK, KP = 32 * KBLK;
     constexpr int LDD = NP + 4, LDZ = KP + 4;

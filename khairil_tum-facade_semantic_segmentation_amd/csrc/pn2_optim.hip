@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ para
                                                         long long n, const float *__restrict__ lr, const float *__restrict__ state,
                                                         float beta1, float beta2, float eps, float weight_decay, float grad_scale)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     const float step_size = *lr / state[1];
     const float bc2_sqrt = state[2];
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void adam_step_scattered_kernel(float *__restr
                                                                   float beta1, float beta2, float eps, float weight_decay,
                                                                   float grad_scale)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     __shared__ unsigned sOff[ADAM_MAX_TENSORS + 1];
     __shared__ const float *sGrad[ADAM_MAX_TENSORS];
     for (int i = threadIdx.x; i <= t.n; i += 256) sOff[i] = t.off[i];

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(
     const float *__restrict__ points2, const int64_t *__restrict__ idx3, const float *__restrict__ weight3,
     long long total, int N, int S, int D, float *__restrict__ out)
 {
+    PN2_MAIN_BRANCH_PRIORITY();
     const int dv = D / VEC;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {

@@ -13,6 +13,12 @@ import torch.distributed as dist
 
 from . import head, mlp
 
+# LAB switch, measurement only (the step is then WRONG for any batch but the one it was captured on): the captured step
+# keeps the first batch's geometry pyramid and has no geometry branch -- what the main branch costs when nothing runs beside it
+_FREEZE_GEOMETRY = os.environ.get("PN2_LAB_FREEZE_GEOMETRY", "0") == "1"
+# PN2_HANDOVER_ON_MAIN=1: the next batch's pyramid is copied into the static buffers by the MAIN branch after a single join
+# (fork at the start, join after backward), instead of by the side branch behind a second cross-queue dependency
+_HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "0") == "1"
 _DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 
@@ -400,13 +406,18 @@ class SemSegTrainer:
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fwd_bwd, pool=pool):
             geo = new_geo = None
-            if self.prefetch:
+            if self.prefetch and _FREEZE_GEOMETRY:
+                geo = self._geo_cur                                       # lab: no side branch at all (see _FREEZE_GEOMETRY)
+            elif self.prefetch:
                 new_geo = self._launch_prefetch(self._static_next_x)      # fork: side branch of the graph
                 with torch.cuda.stream(self._side):
                     new_flat = self._pack_geometry(new_geo)
                 geo = self._geo_cur
             self._static_loss = self._forward_backward(self._static_x, self._static_y, geo)
-            if self.prefetch:
+            if self.prefetch and not _FREEZE_GEOMETRY and _HANDOVER_ON_MAIN:
+                torch.cuda.current_stream().wait_stream(self._side)       # the only join; backward no longer reads `cur`
+                self._geo_flat.copy_(new_flat)
+            elif self.prefetch and not _FREEZE_GEOMETRY:
                 self._side.wait_stream(torch.cuda.current_stream())       # backward no longer reads `cur`
                 with torch.cuda.stream(self._side):
                     self._geo_flat.copy_(new_flat)
@@ -415,7 +426,7 @@ class SemSegTrainer:
                 flat = self.grads.pack()                # .grad become views of one flat buffer
                 if not exchange:
                     self.flat_adam.step(flat)
-            if self.prefetch:
+            if self.prefetch and not _FREEZE_GEOMETRY and not _HANDOVER_ON_MAIN:
                 torch.cuda.current_stream().wait_stream(self._side)       # join
         if exchange:
             # the all-reduce (sum) runs eagerly between the two graphs; the 1/world goes into the Adam pass
