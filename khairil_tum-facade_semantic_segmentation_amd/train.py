@@ -16,9 +16,10 @@ from . import head, mlp
 # LAB switch, measurement only (the step is then WRONG for any batch but the one it was captured on): the captured step
 # keeps the first batch's geometry pyramid and has no geometry branch -- what the main branch costs when nothing runs beside it
 _FREEZE_GEOMETRY = os.environ.get("PN2_LAB_FREEZE_GEOMETRY", "0") == "1"
-# PN2_HANDOVER_ON_MAIN=1: the next batch's pyramid is copied into the static buffers by the MAIN branch after a single join
-# (fork at the start, join after backward), instead of by the side branch behind a second cross-queue dependency
-_HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "0") == "1"
+# The next batch's pyramid is copied into the static buffers by the MAIN branch after the graph's single join (fork at the
+# start, join after backward: -9 us per step); PN2_HANDOVER_ON_MAIN=0: by the side branch behind a second cross-queue
+# dependency, the optimizer running beside the copy (the form of rounds 1-2)
+_HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "1") == "1"
 _DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 
@@ -378,8 +379,8 @@ class SemSegTrainer:
         self._static_y = target.clone()
         if self.prefetch:
             # static pyramid buffer `cur`: read by forward and backward of a replay; the side branch of the
-            # same replay computes the next batch's pyramid and, once backward is done, copies it into
-            # `cur` while the optimizer runs on the main stream (so no copy sits on the critical path)
+            # same replay computes the next batch's pyramid, and once backward is done it is copied into `cur`
+            # (one 6 us copy: see _HANDOVER_ON_MAIN)
             self._static_next_x = blocks_cf.clone()
             torch.cuda.current_stream().wait_stream(self._side)
             first = self._geometry_of(self._static_x)
