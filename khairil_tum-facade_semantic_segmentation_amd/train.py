@@ -20,6 +20,12 @@ _FREEZE_GEOMETRY = os.environ.get("PN2_LAB_FREEZE_GEOMETRY", "0") == "1"
 # start, join after backward: -9 us per step); PN2_HANDOVER_ON_MAIN=0: by the side branch behind a second cross-queue
 # dependency, the optimizer running beside the copy (the form of rounds 1-2)
 _HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "1") == "1"
+# PN2_SEPARATE_GEOMETRY_GRAPH=1: the geometry of the next batch is a hipGraph of its own, replayed on the side stream, instead
+# of a branch of the step's graph.  The hipGraph executor keeps ONE branch of a graph on the launch stream and moves the other
+# to a queue of its own -- for the step's graph the branch that moved was the main one, and every step then paid a cross-queue
+# signal at its start (fork) and at its end (join); rocprofv3 shows the single-branch graph running 135 kernels back to back
+# (2.7 us of gaps in 2365 us).  With two graphs the main stream only ever waits on an event recorded one step earlier.
+_SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "0") == "1"
 _DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 
@@ -212,7 +218,7 @@ class SemSegTrainer:
         self._static_next_x = None
         self._graph_warmup = graph_warmup
         self._eager_steps = 0
-        self._g_fwd_bwd = self._g_opt = None
+        self._g_fwd_bwd = self._g_opt = self._g_geo = None
         self._static_x = self._static_y = self._static_loss = None
 
     def broadcast_parameters(self, src=0):
@@ -404,18 +410,33 @@ class SemSegTrainer:
                 off += nbytes + (0 if padt is None else padt.numel())
             torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
+        separate = self.prefetch and _SEPARATE_GEOMETRY_GRAPH and not _FREEZE_GEOMETRY
+        self._g_geo = None
+        if separate:
+            # the next batch's pyramid as a graph of its OWN on the side stream, written into a second static buffer; the step's
+            # graph then has ONE branch and stays on the stream it is launched on (see _SEPARATE_GEOMETRY_GRAPH)
+            self._geo_next_flat = self._geo_flat.clone()
+            self._geo_ready = torch.cuda.Event()
+            self._side.wait_stream(torch.cuda.current_stream())
+            self._g_geo = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_geo, stream=self._side):     # a pool of its own: the two graphs run side by side
+                self._geo_next_flat.copy_(self._pack_geometry(self._geometry_of(self._static_next_x)))
+            torch.cuda.current_stream().wait_stream(self._side)
+            torch.cuda.synchronize()
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fwd_bwd, pool=pool):
             geo = new_geo = None
-            if self.prefetch and _FREEZE_GEOMETRY:
-                geo = self._geo_cur                                       # lab: no side branch at all (see _FREEZE_GEOMETRY)
+            if (self.prefetch and _FREEZE_GEOMETRY) or separate:
+                geo = self._geo_cur                                       # no side branch in this graph
             elif self.prefetch:
                 new_geo = self._launch_prefetch(self._static_next_x)      # fork: side branch of the graph
                 with torch.cuda.stream(self._side):
                     new_flat = self._pack_geometry(new_geo)
                 geo = self._geo_cur
             self._static_loss = self._forward_backward(self._static_x, self._static_y, geo)
-            if self.prefetch and not _FREEZE_GEOMETRY and _HANDOVER_ON_MAIN:
+            if separate:
+                pass
+            elif self.prefetch and not _FREEZE_GEOMETRY and _HANDOVER_ON_MAIN:
                 torch.cuda.current_stream().wait_stream(self._side)       # the only join; backward no longer reads `cur`
                 self._geo_flat.copy_(new_flat)
             elif self.prefetch and not _FREEZE_GEOMETRY:
@@ -427,7 +448,7 @@ class SemSegTrainer:
                 flat = self.grads.pack()                # .grad become views of one flat buffer
                 if not exchange:
                     self.flat_adam.step(flat)
-            if self.prefetch and not _FREEZE_GEOMETRY and not _HANDOVER_ON_MAIN:
+            if self.prefetch and not _FREEZE_GEOMETRY and not _HANDOVER_ON_MAIN and not separate:
                 torch.cuda.current_stream().wait_stream(self._side)       # join
         if exchange:
             # the all-reduce (sum) runs eagerly between the two graphs; the 1/world goes into the Adam pass
@@ -461,14 +482,26 @@ class SemSegTrainer:
         if target.data_ptr() != self._static_y.data_ptr():
             self._static_y.copy_(target)
         if self.prefetch:
+            main = torch.cuda.current_stream()
             if not self._same_batch(self._geo_next_src, blocks_cf):
                 # the pyramid in `cur` was computed for another batch (the caller did not announce this one as
                 # next_blocks_cf): compute this batch's pyramid now, on the main stream, before the replay reads it
                 self._geo_flat.copy_(self._pack_geometry(self._geometry_of(self._static_x)))
+            elif self._g_geo is not None:
+                # the side stream's graph left this batch's pyramid in the second buffer during the previous step: the
+                # event it recorded then has long fired, the main stream does not stall on it
+                main.wait_event(self._geo_ready)
+                self._geo_flat.copy_(self._geo_next_flat)
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._static_next_x.copy_(nxt)
             self._geo_next_src = self._identity(nxt)
+            if self._g_geo is not None:
+                self._side.wait_stream(main)                    # the copies above: the second buffer and the next input are free / set
         self._g_fwd_bwd.replay()
+        if self.prefetch and self._g_geo is not None:
+            with torch.cuda.stream(self._side):
+                self._g_geo.replay()
+                self._geo_ready.record()
         if self._g_opt is not None:
             dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)
             self._g_opt.replay()
