@@ -219,6 +219,17 @@ def _padded(width, pad_to):
     return (width + pad_to - 1) // pad_to * pad_to
 
 
+_NEXT_GROUPED_OUT = None
+
+
+def place_next_grouped(out):
+    """The NEXT grouped-rows result of ball_query_group goes into `out` ([B,S,K,ldg] fp32, contiguous) instead of a fresh
+    tensor, if the shapes agree (otherwise the offer lapses).  The trainer places the first level's rows -- 25 MB of the
+    27 MB geometry pyramid -- directly in the buffer the next step reads them from."""
+    global _NEXT_GROUPED_OUT
+    _NEXT_GROUPED_OUT = out
+
+
 def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, pad_to=1, plan=None):
     dev = _dev(xyz, new_xyz, points)
     lib = _lib.load()
@@ -227,7 +238,15 @@ def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, p
     D = 0 if points is None else points.shape[2]
     ldg = _padded(3 + D, pad_to)
     idx = torch.empty((B, S, nsample), dtype=torch.int64, device=dev)
-    grouped = torch.empty((B, S, nsample, ldg), dtype=torch.float32, device=dev) if want_grouped else None
+    grouped = None
+    if want_grouped:
+        global _NEXT_GROUPED_OUT
+        placed, _NEXT_GROUPED_OUT = _NEXT_GROUPED_OUT, None
+        if placed is not None and tuple(placed.shape) == (B, S, nsample, ldg) and placed.dtype == torch.float32 \
+                and placed.device == dev and placed.is_contiguous():
+            grouped = placed                     # the caller's buffer (place_next_grouped): no copy of the rows later
+        else:
+            grouped = torch.empty((B, S, nsample, ldg), dtype=torch.float32, device=dev)
     if plan is not None and not (plan.matches(B, N, S, plan.D, radius, xyz, new_xyz) and (plan.D == D or not want_grouped)):
         plan = None
     # No plan given: the self-contained entry (one launch).  Building a plan for ONE query costs more than it saves

@@ -20,12 +20,13 @@ _FREEZE_GEOMETRY = os.environ.get("PN2_LAB_FREEZE_GEOMETRY", "0") == "1"
 # start, join after backward: -9 us per step); PN2_HANDOVER_ON_MAIN=0: by the side branch behind a second cross-queue
 # dependency, the optimizer running beside the copy (the form of rounds 1-2)
 _HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "1") == "1"
-# PN2_SEPARATE_GEOMETRY_GRAPH=1: the geometry of the next batch is a hipGraph of its own, replayed on the side stream, instead
-# of a branch of the step's graph.  The hipGraph executor keeps ONE branch of a graph on the launch stream and moves the other
+# The geometry of the next batch is a hipGraph of its own, replayed on the side stream (PN2_SEPARATE_GEOMETRY_GRAPH=0: a branch
+# of the step's graph, the form of rounds 1-2).  The hipGraph executor keeps ONE branch of a graph on the launch stream and moves the other
 # to a queue of its own -- for the step's graph the branch that moved was the main one, and every step then paid a cross-queue
 # signal at its start (fork) and at its end (join); rocprofv3 shows the single-branch graph running 135 kernels back to back
-# (2.7 us of gaps in 2365 us).  With two graphs the main stream only ever waits on an event recorded one step earlier.
-_SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "0") == "1"
+# (2.7 us of gaps in 2365 us).  With two graphs the main stream only ever waits on an event recorded one step earlier, and the
+# first level's grouped rows (25 MB) are written where the next step reads them: 2.59 -> 2.53 ms per step.
+_SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "1") == "1"
 _DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 
@@ -319,6 +320,31 @@ class SemSegTrainer:
             geo = self._geometry_of(next_blocks_cf)
         return geo
 
+    def _fill_next_pyramid(self):
+        """The pyramid of `_static_next_x` into the second static buffer.  The first level's grouped rows (25 of the 27 MB)
+        are written by the query launch itself (ops.place_next_grouped); the small tensors before and behind them are
+        concatenated and copied -- packing everything and copying the pack moved the rows twice."""
+        from . import ops
+        big = max(range(len(self._geo_shapes)), key=lambda i: 0 if self._geo_shapes[i] is None else self._geo_offs[i + 1] - self._geo_offs[i])
+        dtype, shape = self._geo_shapes[big]
+        o0, o1 = self._geo_offs[big], self._geo_offs[big + 1]
+        pad = 0 if self._geo_pads[big] is None else self._geo_pads[big].numel()
+        view = self._geo_next_flat[o0:o1 - pad].view(dtype).view(shape)
+        placeable = dtype == torch.float32 and len(shape) == 4
+        if placeable:
+            ops.place_next_grouped(view)
+        geo = self._geometry_of(self._static_next_x)
+        ops.place_next_grouped(None)
+        if placeable and geo[big] is not None and geo[big].data_ptr() == view.data_ptr():
+            if big > 0:
+                self._geo_next_flat[:o0].copy_(pack_segments(geo[:big], self._geo_pads[:big]))
+            if big + 1 < len(geo):
+                self._geo_next_flat[o1:].copy_(pack_segments(geo[big + 1:], self._geo_pads[big + 1:]))
+            if pad:
+                self._geo_next_flat[o1 - pad:o1].zero_()
+        else:
+            self._geo_next_flat.copy_(self._pack_geometry(geo))
+
     def _pack_geometry(self, geo):
         """The pyramid's tensors as one uint8 buffer (segment layout fixed at capture time)."""
         return pack_segments(geo, self._geo_pads)
@@ -400,14 +426,17 @@ class SemSegTrainer:
                 off += nbytes + pad
             self._geo_flat = torch.empty(off, dtype=torch.uint8, device=blocks_cf.device)
             self._geo_flat.copy_(self._pack_geometry(first))
-            self._geo_cur, off = [], 0
+            self._geo_cur, self._geo_offs, off = [], [], 0
             for t, padt in zip(first, self._geo_pads):
+                self._geo_offs.append(off)
                 if t is None:
                     self._geo_cur.append(None)
                     continue
                 nbytes = t.numel() * t.element_size()
                 self._geo_cur.append(self._geo_flat[off:off + nbytes].view(t.dtype).view(t.shape))
                 off += nbytes + (0 if padt is None else padt.numel())
+            self._geo_offs.append(off)
+            self._geo_shapes = [None if t is None else (t.dtype, tuple(t.shape)) for t in first]
             torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         separate = self.prefetch and _SEPARATE_GEOMETRY_GRAPH and not _FREEZE_GEOMETRY
@@ -420,7 +449,7 @@ class SemSegTrainer:
             self._side.wait_stream(torch.cuda.current_stream())
             self._g_geo = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_geo, stream=self._side):     # a pool of its own: the two graphs run side by side
-                self._geo_next_flat.copy_(self._pack_geometry(self._geometry_of(self._static_next_x)))
+                self._fill_next_pyramid()
             torch.cuda.current_stream().wait_stream(self._side)
             torch.cuda.synchronize()
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
