@@ -27,6 +27,9 @@ _HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "1") == "1"
 # (2.7 us of gaps in 2365 us).  With two graphs the main stream only ever waits on an event recorded one step earlier, and the
 # first level's grouped rows (25 MB) are written where the next step reads them: 2.59 -> 2.53 ms per step.
 _SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "1") == "1"
+# PN2_ALTERNATE_STEP_GRAPHS=1 (single process, with the geometry graph): two captured step graphs that read the pyramid from two
+# buffers in turn, so that the 27 MB hand-over copy disappears from the main stream
+_ALTERNATE_STEP_GRAPHS = os.environ.get("PN2_ALTERNATE_STEP_GRAPHS", "0") == "1"
 _DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 
@@ -219,7 +222,7 @@ class SemSegTrainer:
         self._static_next_x = None
         self._graph_warmup = graph_warmup
         self._eager_steps = 0
-        self._g_fwd_bwd = self._g_opt = self._g_geo = None
+        self._g_fwd_bwd = self._g_opt = self._g_geo = self._alt = None
         self._static_x = self._static_y = self._static_loss = None
 
     def broadcast_parameters(self, src=0):
@@ -320,16 +323,17 @@ class SemSegTrainer:
             geo = self._geometry_of(next_blocks_cf)
         return geo
 
-    def _fill_next_pyramid(self):
-        """The pyramid of `_static_next_x` into the second static buffer.  The first level's grouped rows (25 of the 27 MB)
+    def _fill_next_pyramid(self, flat=None):
+        """The pyramid of `_static_next_x` into a static buffer (default: the second one).  The first level's grouped rows (25 of the 27 MB)
         are written by the query launch itself (ops.place_next_grouped); the small tensors before and behind them are
         concatenated and copied -- packing everything and copying the pack moved the rows twice."""
         from . import ops
+        flat = self._geo_next_flat if flat is None else flat
         big = max(range(len(self._geo_shapes)), key=lambda i: 0 if self._geo_shapes[i] is None else self._geo_offs[i + 1] - self._geo_offs[i])
         dtype, shape = self._geo_shapes[big]
         o0, o1 = self._geo_offs[big], self._geo_offs[big + 1]
         pad = 0 if self._geo_pads[big] is None else self._geo_pads[big].numel()
-        view = self._geo_next_flat[o0:o1 - pad].view(dtype).view(shape)
+        view = flat[o0:o1 - pad].view(dtype).view(shape)
         placeable = dtype == torch.float32 and len(shape) == 4
         if placeable:
             ops.place_next_grouped(view)
@@ -337,13 +341,24 @@ class SemSegTrainer:
         ops.place_next_grouped(None)
         if placeable and geo[big] is not None and geo[big].data_ptr() == view.data_ptr():
             if big > 0:
-                self._geo_next_flat[:o0].copy_(pack_segments(geo[:big], self._geo_pads[:big]))
+                flat[:o0].copy_(pack_segments(geo[:big], self._geo_pads[:big]))
             if big + 1 < len(geo):
-                self._geo_next_flat[o1:].copy_(pack_segments(geo[big + 1:], self._geo_pads[big + 1:]))
+                flat[o1:].copy_(pack_segments(geo[big + 1:], self._geo_pads[big + 1:]))
             if pad:
-                self._geo_next_flat[o1 - pad:o1].zero_()
+                flat[o1 - pad:o1].zero_()
         else:
-            self._geo_next_flat.copy_(self._pack_geometry(geo))
+            flat.copy_(self._pack_geometry(geo))
+
+    def _views_of(self, flat):
+        """The pyramid's tensors as views of a flat byte buffer with the layout fixed at capture time."""
+        views = []
+        for i, sh in enumerate(self._geo_shapes):
+            if sh is None:
+                views.append(None)
+                continue
+            pad = 0 if self._geo_pads[i] is None else self._geo_pads[i].numel()
+            views.append(flat[self._geo_offs[i]:self._geo_offs[i + 1] - pad].view(sh[0]).view(sh[1]))
+        return views
 
     def _pack_geometry(self, geo):
         """The pyramid's tensors as one uint8 buffer (segment layout fixed at capture time)."""
@@ -452,6 +467,21 @@ class SemSegTrainer:
                 self._fill_next_pyramid()
             torch.cuda.current_stream().wait_stream(self._side)
             torch.cuda.synchronize()
+        # Two alternating step graphs (single process only): step graph p reads pyramid buffer p while geometry graph p fills
+        # buffer 1 - p for the step after it -- no 27 MB hand-over copy on the main stream (see _ALTERNATE_STEP_GRAPHS)
+        self._alt = None
+        alternate = separate and _ALTERNATE_STEP_GRAPHS and not exchange
+        if alternate:
+            bufs = [self._geo_flat, self._geo_next_flat]
+            views = [self._geo_cur, self._views_of(self._geo_next_flat)]
+            geo_pool = self._g_geo.pool()
+            self._side.wait_stream(torch.cuda.current_stream())
+            g_geo1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_geo1, stream=self._side, pool=geo_pool):
+                self._fill_next_pyramid(bufs[0])
+            torch.cuda.current_stream().wait_stream(self._side)
+            torch.cuda.synchronize()
+            self._alt = {"geo": [self._g_geo, g_geo1], "main": [None, None], "loss": [None, None], "bufs": bufs, "p": 0}
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fwd_bwd, pool=pool):
             geo = new_geo = None
@@ -479,6 +509,14 @@ class SemSegTrainer:
                     self.flat_adam.step(flat)
             if self.prefetch and not _FREEZE_GEOMETRY and not _HANDOVER_ON_MAIN and not separate:
                 torch.cuda.current_stream().wait_stream(self._side)       # join
+        if alternate:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, pool=pool):
+                loss1 = self._forward_backward(self._static_x, self._static_y, views[1])
+                if not self.flat_adam.step_scattered([p.grad for p in self.grads.params]):
+                    self.flat_adam.step(self.grads.pack())
+            self._alt["main"] = [self._g_fwd_bwd, g1]
+            self._alt["loss"] = [self._static_loss, loss1]
         if exchange:
             # the all-reduce (sum) runs eagerly between the two graphs; the 1/world goes into the Adam pass
             self._g_opt = torch.cuda.CUDAGraph()
@@ -512,25 +550,39 @@ class SemSegTrainer:
             self._static_y.copy_(target)
         if self.prefetch:
             main = torch.cuda.current_stream()
+            alt = self._alt
             if not self._same_batch(self._geo_next_src, blocks_cf):
                 # the pyramid in `cur` was computed for another batch (the caller did not announce this one as
                 # next_blocks_cf): compute this batch's pyramid now, on the main stream, before the replay reads it
-                self._geo_flat.copy_(self._pack_geometry(self._geometry_of(self._static_x)))
+                if alt is not None:
+                    main.wait_event(self._geo_ready)        # (the side graph may still be writing this buffer)
+                (self._geo_flat if alt is None else alt["bufs"][alt["p"]]).copy_(self._pack_geometry(self._geometry_of(self._static_x)))
             elif self._g_geo is not None:
-                # the side stream's graph left this batch's pyramid in the second buffer during the previous step: the
+                # the side stream's graph left this batch's pyramid in the other buffer during the previous step: the
                 # event it recorded then has long fired, the main stream does not stall on it
                 main.wait_event(self._geo_ready)
-                self._geo_flat.copy_(self._geo_next_flat)
+                if alt is None:
+                    self._geo_flat.copy_(self._geo_next_flat)
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._static_next_x.copy_(nxt)
             self._geo_next_src = self._identity(nxt)
             if self._g_geo is not None:
                 self._side.wait_stream(main)                    # the copies above: the second buffer and the next input are free / set
-        self._g_fwd_bwd.replay()
-        if self.prefetch and self._g_geo is not None:
+        if self.prefetch and self._alt is not None:
+            alt = self._alt
+            p = alt["p"]
+            alt["main"][p].replay()                             # reads pyramid buffer p
             with torch.cuda.stream(self._side):
-                self._g_geo.replay()
+                alt["geo"][p].replay()                          # fills buffer 1 - p for the next step
                 self._geo_ready.record()
+            self._static_loss = alt["loss"][p]
+            alt["p"] = p ^ 1
+        else:
+            self._g_fwd_bwd.replay()
+            if self.prefetch and self._g_geo is not None:
+                with torch.cuda.stream(self._side):
+                    self._g_geo.replay()
+                    self._geo_ready.record()
         if self._g_opt is not None:
             dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)
             self._g_opt.replay()
