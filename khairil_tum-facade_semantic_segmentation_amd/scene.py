@@ -8,6 +8,8 @@ Here the scene's points are bucketed once into a 2-D grid so a window touches on
 overlaps, and votes are scattered on the device straight from the network's log-probabilities.
 Block / window semantics and the numpy RNG call sequence are those of the reference, so the same
 seed yields the same blocks (tests/test_scene_cpu.py, against outputs of the reference's code)."""
+import os
+
 import numpy as np
 
 
@@ -470,6 +472,10 @@ def shard_batches(num_blocks, batch_size, rank=0, world=1):
     return list(range(0, num_blocks, batch_size))[rank::world]
 
 
+# PN2_INFER_TWO_GRAPHS=0: the forked single graph of rounds 1-2 (the pyramid of the next sub-batch as a branch of the forward's graph)
+_TWO_GRAPHS = os.environ.get("PN2_INFER_TWO_GRAPHS", "1") == "1"
+
+
 class BlockInferencer:
     """Eval-mode forward passes over fixed-shape sub-batches [B, C, N] as ONE replayed hipGraph: while sub-batch i runs
     through the MLP stacks, the FPS / ball-query / 3-NN pyramid of sub-batch i+1 (with the first level's grouped rows and
@@ -531,6 +537,45 @@ class BlockInferencer:
                 off += nbytes + (0 if padt is None else padt.numel())
             torch.cuda.synchronize(self.dev)
             self._captured_ptrs = self._param_ptrs()
+            self._two = None
+            if _TWO_GRAPHS:
+                # The pyramid of the next sub-batch as a hipGraph of its OWN on the side stream and two forward graphs that read
+                # two pyramid buffers in turn: a forked graph keeps only one branch on its launch stream, and it was the
+                # forward that moved to another queue (train.py, _SEPARATE_GEOMETRY_GRAPH); no hand-over copy either.
+                flat2 = self._flat.clone()
+                views2, off = [], 0
+                for t, padt in zip(first, self._pads):
+                    if t is None:
+                        views2.append(None)
+                        continue
+                    nbytes = t.numel() * t.element_size()
+                    views2.append(flat2[off:off + nbytes].view(t.dtype).view(t.shape))
+                    off += nbytes + (0 if padt is None else padt.numel())
+                bufs, views = [self._flat, flat2], [self._cur, views2]
+                main = torch.cuda.current_stream()
+                geos, fwds, logps = [], [], []
+                gpool = None
+                for p in (0, 1):
+                    self._side.wait_stream(main)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._side, **({} if gpool is None else {"pool": gpool})):
+                        bufs[1 - p].copy_(self._pack(self._geometry_of(self.next_x)))      # fills the OTHER buffer
+                    gpool = g.pool()
+                    main.wait_stream(self._side)
+                    torch.cuda.synchronize(self.dev)
+                    geos.append(g)
+                fpool = None
+                for p in (0, 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, **({} if fpool is None else {"pool": fpool})):
+                        logp, _ = self.model(self.cur_x, geometry=views[p][:-2], prepared=(views[p][-2], views[p][-1]))
+                    fpool = g.pool()
+                    fwds.append(g)
+                    logps.append(logp)
+                self._two = {"geo": geos, "fwd": fwds, "logp": logps, "bufs": bufs, "p": 0, "ready": torch.cuda.Event()}
+                self._graph = fwds[0]
+                self.logp = logps[0]
+                return
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 main = torch.cuda.current_stream()
@@ -566,14 +611,32 @@ class BlockInferencer:
                 self._graph = None                                # the parameters live elsewhere now: the graph reads stale memory
             if self._graph is None:
                 self._capture()
+            two = self._two
+            main = torch.cuda.current_stream()
+            if two is not None:
+                main.wait_event(two["ready"])                     # (a geometry graph of an earlier run)
             load(self.next_x, batches[0])
-            self._flat.copy_(self._pack(self._geometry_of(self.next_x)))   # the first pyramid, on the main stream
+            (self._flat if two is None else two["bufs"][two["p"]]).copy_(self._pack(self._geometry_of(self.next_x)))   # the first pyramid
             for i, blocks in enumerate(batches):
                 nxt = batches[i + 1] if i + 1 < len(batches) else blocks
                 b = blocks.shape[0]
+                if two is None:
+                    load(self.next_x, nxt)
+                    self._graph.replay()
+                    consume(i, self.logp[:b])
+                    continue
+                p = two["p"]
+                if i > 0:
+                    main.wait_event(two["ready"])                 # the side graph has read next_x and filled buffer p
                 load(self.next_x, nxt)
-                self._graph.replay()
+                self._side.wait_stream(main)
+                two["fwd"][p].replay()                            # reads pyramid buffer p
+                with torch.cuda.stream(self._side):
+                    two["geo"][p].replay()                        # the pyramid of next_x into buffer 1 - p
+                    two["ready"].record()
+                self.logp = two["logp"][p]
                 consume(i, self.logp[:b])
+                two["p"] = p ^ 1
 
 
 def scene_metrics(pred_label, labels, num_classes):

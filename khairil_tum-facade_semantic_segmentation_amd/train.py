@@ -551,18 +551,16 @@ class SemSegTrainer:
         if self.prefetch:
             main = torch.cuda.current_stream()
             alt = self._alt
+            if self._g_geo is not None:
+                # the side stream's graph of the previous step reads `_static_next_x` and fills the other pyramid buffer: both
+                # are touched below.  Its event was recorded one step ago and has long fired -- the main stream does not stall
+                main.wait_event(self._geo_ready)
             if not self._same_batch(self._geo_next_src, blocks_cf):
                 # the pyramid in `cur` was computed for another batch (the caller did not announce this one as
                 # next_blocks_cf): compute this batch's pyramid now, on the main stream, before the replay reads it
-                if alt is not None:
-                    main.wait_event(self._geo_ready)        # (the side graph may still be writing this buffer)
                 (self._geo_flat if alt is None else alt["bufs"][alt["p"]]).copy_(self._pack_geometry(self._geometry_of(self._static_x)))
-            elif self._g_geo is not None:
-                # the side stream's graph left this batch's pyramid in the other buffer during the previous step: the
-                # event it recorded then has long fired, the main stream does not stall on it
-                main.wait_event(self._geo_ready)
-                if alt is None:
-                    self._geo_flat.copy_(self._geo_next_flat)
+            elif self._g_geo is not None and alt is None:
+                self._geo_flat.copy_(self._geo_next_flat)    # the pyramid the side graph left for this batch
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._static_next_x.copy_(nxt)
             self._geo_next_src = self._identity(nxt)
