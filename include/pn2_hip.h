@@ -311,6 +311,13 @@ int pn2_head_logits_backward(const float *glogp, const float *logp, const float 
  * un-dropped y.  pn2_dropout_mask writes that mask ([M][K] bytes, 1 = kept) for tests. */
 int pn2_head_logits_dropout(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K,
                             int C, const unsigned long long *drop_seed, float drop_p, pn2_stream_t stream);
+/* The forward with a COUNTED seed: state[0] = base seed, state[1] = calls so far, state[2] = 0 (ticket), all on the device; the
+ * kernel hashes its seed from (base, calls), writes it to *seed_out (what the backward takes as drop_seed) and its last
+ * workgroup counts the call.  No random-number launch in front of the head, and a captured step draws nothing from torch's
+ * generator (a replay of a graph that does is preceded by two fill launches for the generator's state). */
+int pn2_head_logits_dropout_counted(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K,
+                                    int C, unsigned long long *state, unsigned long long *seed_out, float drop_p,
+                                    pn2_stream_t stream);
 int pn2_head_logits_dropout_backward(const float *glogp, const float *logp, const float *y, int ldy, const float *w,
                                      float *gy, int ldgy, float *partial, float *dw, float *db, int M, int K, int C,
                                      const unsigned long long *drop_seed, float drop_p, pn2_stream_t stream);

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pn2_head_logits": [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],
     "pn2_head_logits_partials": [_ci],
     "pn2_head_logits_dropout": [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp, _cf, _vp],
+    "pn2_head_logits_dropout_counted": [_vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp, _cf, _vp],
     "pn2_head_logits_dropout_backward": [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp, _cf, _vp],
     "pn2_dropout_mask": [_vp, _cf, _cl, _ci, _vp, _vp],
     "pn2_head_logits_backward": [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _ci, _vp],

@@ -21,7 +21,32 @@ struct DropArgs {
     const unsigned long long *seed;
     unsigned thresh;              // p * 2^32: an element is dropped when its hash is below
     float scale;                  // 1 / (1 - p)
+    // counted form (forward only): the seed is hashed from state[0] (base) and state[1] (calls so far), written to
+    // *seed_out for the backward, and the workgroup that finishes last counts the call (state[2] = ticket)
+    unsigned long long *state, *seed_out;
 };
+__device__ __forceinline__ bool drop_on(const DropArgs &d) { return d.seed != nullptr || d.state != nullptr; }
+__device__ __forceinline__ unsigned long long drop_seed_value(const DropArgs &d)
+{
+    if (d.state) {
+        unsigned long long x = d.state[0] + (d.state[1] + 1ull) * 0x9E3779B97F4A7C15ull;      // splitmix64 finaliser
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    }
+    return d.seed ? *d.seed : 0ull;
+}
+// end of a counted forward launch (every thread of the workgroup has read the state long before: barriers lie between)
+__device__ __forceinline__ void drop_count_call(const DropArgs &d, unsigned long long seed)
+{
+    if (!d.state || threadIdx.x != 0) return;
+    if (blockIdx.x == 0) *d.seed_out = seed;
+    unsigned *ticket = reinterpret_cast<unsigned *>(d.state + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        *ticket = 0u;
+        d.state[1] = d.state[1] + 1ull;
+    }
+}
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned row, unsigned col, unsigned thresh)
 {
     unsigned h = ((unsigned)seed ^ (row * 0x9E3779B1u)) + (((unsigned)(seed >> 32)) ^ (col * 0x85EBCA77u));
@@ -42,7 +67,7 @@ __device__ __forceinline__ float4 drop4(float4 v, const DropArgs &d, unsigned lo
 __device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy, int row0, int M, int k4n, float *__restrict__ sY, int tid,
                                            const DropArgs &d)
 {
-    const unsigned long long seed = d.seed ? *d.seed : 0ull;
+    const unsigned long long seed = drop_seed_value(d);
     constexpr int NI = HD_ROWS * (HD_KMAX / 4) / HD_THREADS;          // 8
     const int total = HD_ROWS * k4n;
     float4 v[NI];
@@ -58,7 +83,7 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy,
         if (e < total) {
             const int r = e / k4n, q = e - r * k4n;
             float4 o = row0 + r < M ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.seed) o = drop4(o, d, seed, (unsigned)(row0 + r), (unsigned)(4 * q));
+            if (drop_on(d)) o = drop4(o, d, seed, (unsigned)(row0 + r), (unsigned)(4 * q));
             *reinterpret_cast<float4 *>(&sY[r * HD_LDY + 4 * q]) = o;
         }
     }
@@ -130,6 +155,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
         const int rr = e / C;
         o[e] = sL[rr][e - rr * C];
     }
+    if (drop.state) drop_count_call(drop, drop_seed_value(drop));
 }
 
 // K = 128 (the model's head): the 64 x C products of a tile on the matrix cores.  Wave w takes row block w & 1 and
@@ -206,6 +232,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
         const int rr = e / C;
         o[e] = sL[rr][e - rr * C];
     }
+    if (drop.state) drop_count_call(drop, drop_seed_value(drop));
 }
 
 // ---- backward ----------------------------------------------------------------------------------------
@@ -530,6 +557,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 DropArgs make_drop(const unsigned long long *seed, float p)
 {
     DropArgs d;
+    d.state = d.seed_out = nullptr;
     d.seed = (seed && p > 0.f) ? seed : nullptr;
     const double t = (double)p * 4294967296.0;
     d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
@@ -557,12 +585,32 @@ PN2_EXPORT int pn2_dropout_mask(const unsigned long long *seed, float p, long lo
     return PN2_LAUNCH_RC();
 }
 
+static int head_logits_impl(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K, int C,
+                            const DropArgs &drop, pn2_stream_t stream);
+
 PN2_EXPORT int pn2_head_logits_dropout(const float *y, int ldy, const float *w, const float *bias, float *logp, int M,
                                        int K, int C, const unsigned long long *drop_seed, float drop_p,
                                        pn2_stream_t stream)
 {
     if (drop_p < 0.f || drop_p > 1.f) return PN2_ERR_SHAPE;
-    const DropArgs drop = make_drop(drop_seed, drop_p);
+    return head_logits_impl(y, ldy, w, bias, logp, M, K, C, make_drop(drop_seed, drop_p), stream);
+}
+
+PN2_EXPORT int pn2_head_logits_dropout_counted(const float *y, int ldy, const float *w, const float *bias, float *logp, int M,
+                                               int K, int C, unsigned long long *state, unsigned long long *seed_out,
+                                               float drop_p, pn2_stream_t stream)
+{
+    PN2_REQUIRE_PTR(state); PN2_REQUIRE_PTR(seed_out);
+    if (!(drop_p > 0.f) || drop_p > 1.f) return PN2_ERR_SHAPE;
+    DropArgs drop = make_drop(nullptr, drop_p);
+    drop.state = state;
+    drop.seed_out = seed_out;
+    return head_logits_impl(y, ldy, w, bias, logp, M, K, C, drop, stream);
+}
+
+static int head_logits_impl(const float *y, int ldy, const float *w, const float *bias, float *logp, int M, int K, int C,
+                            const DropArgs &drop, pn2_stream_t stream)
+{
     PN2_REQUIRE_PTR(y); PN2_REQUIRE_PTR(w); PN2_REQUIRE_PTR(logp);
     if (M <= 0 || K <= 0 || C <= 0 || ldy < K) return PN2_ERR_SHAPE;
     if (K > HD_KMAX || C > HD_CMAX || (K & 3) || (ldy & 3) || !aligned16(y) || !aligned16(w)) return PN2_ERR_UNSUPPORTED;

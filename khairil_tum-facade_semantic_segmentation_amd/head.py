@@ -24,9 +24,16 @@ class _HeadLogits(torch.autograd.Function):
         C = w.shape[0]
         w2 = w.reshape(C, K).contiguous()
         logp = torch.empty((M, C), dtype=torch.float32, device=dev)
+        state = _dropout_state(dev) if (seed is None and drop_p > 0.0) else None
         with torch.cuda.device(dev):
-            rc = lib.pn2_head_logits_dropout(_ptr(y), y.stride(0), _ptr(w2), _ptr(b), _ptr(logp), M, K, C, _ptr(seed),
-                                             float(drop_p), _stream(dev))
+            if state is not None:
+                # the seed is hashed from a device counter inside the launch and handed to the backward in `seed`
+                seed = torch.empty(1, dtype=torch.int64, device=dev)
+                rc = lib.pn2_head_logits_dropout_counted(_ptr(y), y.stride(0), _ptr(w2), _ptr(b), _ptr(logp), M, K, C, _ptr(state),
+                                                         _ptr(seed), float(drop_p), _stream(dev))
+            else:
+                rc = lib.pn2_head_logits_dropout(_ptr(y), y.stride(0), _ptr(w2), _ptr(b), _ptr(logp), M, K, C, _ptr(seed),
+                                                 float(drop_p), _stream(dev))
         _lib.check(rc, "pn2_head_logits_dropout")
         ctx.save_for_backward(y, w2, logp)
         ctx.drop_p, ctx.seed = float(drop_p), seed
@@ -67,7 +74,7 @@ def head_logits(y, weight, bias, drop_p=0.0, seed=None):
     y = y.to(torch.float32)
     if y.stride(-1) != 1:
         y = y.contiguous()
-    if drop_p > 0.0 and seed is None:
+    if drop_p > 0.0 and seed is None and (not _COUNTED_DROPOUT or _dropout_state(dev) is None):
         seed = torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.int64, device=dev)
     if drop_p <= 0.0:
         seed = None
@@ -83,6 +90,30 @@ def dropout_mask(seed, drop_p, M, K):
         rc = lib.pn2_dropout_mask(_ptr(seed), float(drop_p), M, K, _ptr(mask), _stream(dev))
     _lib.check(rc, "pn2_dropout_mask")
     return mask.bool()
+
+
+# The head's dropout seed from a device counter (pn2_head_logits_dropout_counted): no random-number launch in front of the head,
+# and a captured training step draws nothing from torch's generator -- replaying a graph that does costs two fill launches for
+# the generator state on top (14 us per step together).  The base seed comes from torch's generator once per device, so
+# torch.manual_seed() still decides the masks.  PN2_COUNTED_DROPOUT=0: a torch.randint per call.
+_COUNTED_DROPOUT = os.environ.get("PN2_COUNTED_DROPOUT", "1") == "1"
+_dropout_states = {}
+
+
+def _dropout_state(dev):
+    """[base seed, calls so far, ticket, unused] on the device; None while a stream capture is running and the state does not
+    exist yet (ensure_ticket_words() before the capture creates it)."""
+    if not _COUNTED_DROPOUT:
+        return None
+    key = (dev.type, dev.index)
+    st = _dropout_states.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = torch.zeros(4, dtype=torch.int64, device=dev)
+        st[0:1] = torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.int64, device=dev)
+        _dropout_states[key] = st
+    return st
 
 
 _tickets = {}
@@ -112,6 +143,7 @@ def ensure_ticket_words(dev):
     key = (dev.type, dev.index, "capture")
     if key not in _tickets and not torch.cuda.is_current_stream_capturing():
         _tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    _dropout_state(dev)
 
 
 class _NLL(torch.autograd.Function):

@@ -154,3 +154,37 @@ def test_head_logits_fused_dropout(env, M, K, C, p):
         assert float((a - r).abs().max()) <= 2e-4 * s + 1e-6, what
     # a dropped element receives no gradient
     assert float(y.grad[~mask].abs().max() if (~mask).any() else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("M,K,C", [(4096, 128, 13), (77, 64, 17)])
+def test_head_dropout_counted_seed(env, M, K, C):
+    """Without an explicit seed the forward hashes its seed from a device counter (pn2_head_logits_dropout_counted): the
+    backward uses the seed the forward reports, every call draws a new mask, the call counter advances by one per call, and
+    the result equals the explicit-seed form run with the reported seed."""
+    torch, head = env
+    if not head._COUNTED_DROPOUT:
+        pytest.skip("PN2_COUNTED_DROPOUT=0")
+    g = torch.Generator().manual_seed(M + C)
+    y = torch.randn(M, K, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(C, K, 1, generator=g) * 0.2).cuda().requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_(True)
+    state = head._dropout_state(y.device)
+    calls0 = int(state[1])
+    outs, seeds = [], []
+    for _ in range(3):
+        out = head.head_logits(y, w, b, drop_p=0.5)
+        seeds.append(out.grad_fn.seed.clone())
+        outs.append(out)
+    assert int(state[1]) == calls0 + 3 and int(state[2]) == 0
+    assert len({int(s) for s in seeds}) == 3
+    assert not torch.equal(outs[0], outs[1])
+    # the same numbers as the explicit-seed form with the seed the forward reported; the backward masks with it
+    y2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (y, w, b))
+    ref = head.head_logits(y2, w2, b2, drop_p=0.5, seed=seeds[2])
+    assert torch.equal(ref, outs[2])
+    go = torch.randn(M, C, generator=g).cuda()
+    outs[2].backward(go)
+    ref.backward(go)
+    assert torch.equal(y.grad, y2.grad) and torch.equal(w.grad, w2.grad) and torch.equal(b.grad, b2.grad)
+    mask = head.dropout_mask(seeds[2], 0.5, M, K)
+    assert float(y.grad[~mask].abs().max()) == 0.0
