@@ -284,6 +284,9 @@ int pn2_copy_pad_cols(const float *src, int lds, int cols_src, float *dst, int l
  * ediv = 1.  Interpolation: src = d out [B][N][D], weight = weight3 [B][N*3], ediv = 3. */
 int pn2_invert_index(const int64_t *idx, int B, long long E, int Nkeys, int32_t *offsets, int32_t *entries,
                      pn2_stream_t stream);
+/* n <= 8 tables of the same batch size in one launch (host arrays of device pointers / sizes, read before return). */
+int pn2_invert_index_many(int n, const int64_t *const *idx, int B, const long long *E, const int *Nkeys,
+                          int32_t *const *offsets, int32_t *const *entries, pn2_stream_t stream);
 int pn2_gather_sum(const float *src, long long rows_src, int lds, int col0, const int32_t *offsets,
                    const int32_t *entries, const float *weight, long long E, int ediv, int B, int Nkeys, int D,
                    float *out, pn2_stream_t stream);

@@ -20,8 +20,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // One workgroup per batch: histogram of the keys, exclusive scan, scatter of the entry ids, then every
 // key's list is put in ascending order (lists are short: 3N/S resp. SK/N entries on average).
-__global__ __launch_bounds__(INV_THREADS) void invert_index_kernel(const int64_t *__restrict__ idx, long long E, int Nkeys,
-                                                                  int32_t *__restrict__ offsets, int32_t *__restrict__ entries)
+__device__ __forceinline__ void invert_index_body(const int64_t *__restrict__ idx, long long E, int Nkeys,
+                                                  int32_t *__restrict__ offsets, int32_t *__restrict__ entries)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *cnt = reinterpret_cast<int *>(smem);                      // [Nkeys + 1] counts -> starts
@@ -88,6 +88,27 @@ __global__ __launch_bounds__(INV_THREADS) void invert_index_kernel(const int64_t
     for (int i = tid; i <= Nkeys; i += INV_THREADS) bo[i] = cnt[i];
     const int total = cnt[Nkeys];
     for (int e = tid; e < E; e += INV_THREADS) be[e] = e < total ? list[e] : -1;
+}
+
+__global__ __launch_bounds__(INV_THREADS) void invert_index_kernel(const int64_t *__restrict__ idx, long long E, int Nkeys,
+                                                                  int32_t *__restrict__ offsets, int32_t *__restrict__ entries)
+{
+    invert_index_body(idx, E, Nkeys, offsets, entries);
+}
+
+// Several tables in one launch (blockIdx.y = table): the four interpolation levels of the network are independent once their
+// 3-NN indices exist, and one-workgroup-per-block launches in a row only add up their latencies (15-27 us each).
+constexpr int INV_MANY_MAX = 8;
+struct InvertMany {
+    const int64_t *idx[INV_MANY_MAX];
+    int32_t *offsets[INV_MANY_MAX], *entries[INV_MANY_MAX];
+    long long E[INV_MANY_MAX];
+    int Nkeys[INV_MANY_MAX];
+};
+__global__ __launch_bounds__(INV_THREADS) void invert_index_many_kernel(InvertMany m)
+{
+    const int j = blockIdx.y;
+    invert_index_body(m.idx[j], m.E[j], m.Nkeys[j], m.offsets[j], m.entries[j]);
 }
 
 // out[b][key][c] = addend[b][key][c] + sum over the key's entries e of w[b][e] * src[b][e / ediv][col0 + c].
@@ -206,6 +227,30 @@ PN2_EXPORT int pn2_invert_index(const int64_t *idx, int B, long long E, int Nkey
     if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(invert_index_kernel), 150 * 1024, lds_memo)) return e;
     hipLaunchKernelGGL(invert_index_kernel, dim3((unsigned)B), dim3(INV_THREADS), lds, static_cast<hipStream_t>(stream_), idx, E,
                        Nkeys, offsets, entries);
+    return PN2_LAUNCH_RC();
+}
+
+PN2_EXPORT int pn2_invert_index_many(int n, const int64_t *const *idx, int B, const long long *E, const int *Nkeys,
+                                     int32_t *const *offsets, int32_t *const *entries, pn2_stream_t stream_)
+{
+    PN2_REQUIRE_PTR(idx); PN2_REQUIRE_PTR(E); PN2_REQUIRE_PTR(Nkeys); PN2_REQUIRE_PTR(offsets); PN2_REQUIRE_PTR(entries);
+    if (n <= 0 || n > INV_MANY_MAX || B < 0) return PN2_ERR_SHAPE;
+    if (B == 0) return PN2_OK;
+    InvertMany m;
+    size_t lds = 0;
+    for (int j = 0; j < INV_MANY_MAX; ++j) {
+        const int i = j < n ? j : n - 1;
+        if (!idx[i] || !offsets[i] || !entries[i]) return PN2_ERR_NULL;
+        if (E[i] <= 0 || Nkeys[i] <= 0) return PN2_ERR_SHAPE;
+        if (E[i] > INV_MAX_ENTRIES || Nkeys[i] > INV_MAX_KEYS) return PN2_ERR_UNSUPPORTED;
+        m.idx[j] = idx[i]; m.offsets[j] = offsets[i]; m.entries[j] = entries[i]; m.E[j] = E[i]; m.Nkeys[j] = Nkeys[i];
+        const size_t need = ((size_t)(2 * Nkeys[i] + 1) + (size_t)E[i]) * sizeof(int);
+        lds = need > lds ? need : lds;
+    }
+    if (lds > 150 * 1024) return PN2_ERR_UNSUPPORTED;
+    static pn2::PerDevice lds_memo;
+    if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(invert_index_many_kernel), 150 * 1024, lds_memo)) return e;
+    hipLaunchKernelGGL(invert_index_many_kernel, dim3((unsigned)B, (unsigned)n), dim3(INV_THREADS), lds, static_cast<hipStream_t>(stream_), m);
     return PN2_LAUNCH_RC();
 }
 

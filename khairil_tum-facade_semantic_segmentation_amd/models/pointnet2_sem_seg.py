@@ -79,11 +79,21 @@ class get_model(nn.Module):
             pair = ops.invert_index(idx, levels[-1].shape[1]) if (i > 0 and _INVERT_GROUPING and for_backward) else None
             inv += list(pair) if pair is not None else [None, None]
             levels.append(new_xyz)
+        idx3s = []
         for lvl in (3, 2, 1, 0):
             idx3, w3 = ops.three_nn(levels[lvl], levels[lvl + 1])
             out += [idx3, w3]
-            pair = ops.invert_index(idx3, levels[lvl + 1].shape[1]) if for_backward else None
-            inv += list(pair) if pair is not None else [None, None]
+            idx3s.append(idx3)
+        if for_backward:
+            # the four transposed tables in one launch (one workgroup per block each: in a row they only add up latencies)
+            keys = [levels[lvl + 1].shape[1] for lvl in (3, 2, 1, 0)]
+            pairs = ops.invert_index_many(idx3s, keys) if idx3s[0].is_cuda else None
+            if pairs is None:
+                pairs = [ops.invert_index(i3, k) for i3, k in zip(idx3s, keys)]
+            for pair in pairs:
+                inv += list(pair) if pair is not None else [None, None]
+        else:
+            inv += [None, None] * 4
         # [0:8] SA, [8:16] FP, [16:24] SA inverses, [24:32] FP inverses, [32] grouped rows of level 1
         return out + inv + ([grouped1] if group_first else [])
 

@@ -326,6 +326,33 @@ def invert_index(idx, nkeys):
     return off, ent
 
 
+def invert_index_many(idxs, nkeys):
+    """invert_index of several index tensors of one batch size in ONE launch: a list of (offsets, entries) pairs, or None
+    when a table is too large for the on-chip transposition (the caller then inverts one by one / keeps the scatter-adds)."""
+    import ctypes
+    if not idxs:
+        return []
+    dev = _dev(*idxs)
+    lib = _lib.load()
+    idxs = [_i64c(t) for t in idxs]
+    B = idxs[0].shape[0]
+    if any(t.shape[0] != B for t in idxs) or len(idxs) > 8:
+        return None
+    Es = [t.numel() // max(B, 1) for t in idxs]
+    offs = [torch.empty((B, k + 1), dtype=torch.int32, device=dev) for k in nkeys]
+    ents = [torch.empty((B, e), dtype=torch.int32, device=dev) for e in Es]
+    n = len(idxs)
+    vp = ctypes.c_void_p * n
+    with torch.cuda.device(dev):
+        rc = lib.pn2_invert_index_many(n, vp(*[t.data_ptr() for t in idxs]), B, (ctypes.c_longlong * n)(*Es),
+                                       (ctypes.c_int * n)(*[int(k) for k in nkeys]), vp(*[t.data_ptr() for t in offs]),
+                                       vp(*[t.data_ptr() for t in ents]), _stream(dev))
+    if rc == -3:                                          # PN2_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc, "pn2_invert_index_many")
+    return list(zip(offs, ents))
+
+
 def _gather_sum(src, rows_src, col0, inv, weight, ediv, nkeys, D, addend=None):
     dev = _dev(src)
     lib = _lib.load()

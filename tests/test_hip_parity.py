@@ -290,6 +290,20 @@ def test_transposed_index_backward_matches_scatter_add(pn2, orc, B, N, S, K, D):
     pn2.ops._ERR.clear()
 
 
+def test_transposed_tables_in_one_launch(pn2):
+    """pn2_invert_index_many: several tables of one batch size in one launch = the tables one by one."""
+    torch = pn2.torch
+    rs = np.random.RandomState(11)
+    shapes = [(64 * 3, 16), (256 * 3, 64), (1024 * 3, 256), (4096 * 3, 1024)]
+    idxs = [torch.from_numpy(rs.randint(0, k, size=(16, e))).cuda() for e, k in shapes]
+    many = pn2.ops.invert_index_many(idxs, [k for _, k in shapes])
+    assert many is not None and len(many) == 4
+    for t, (e, k), (off, ent) in zip(idxs, shapes, many):
+        o1, e1 = pn2.ops.invert_index(t, k)
+        assert torch.equal(off, o1) and torch.equal(ent, e1)
+    assert pn2.ops.invert_index_many([torch.zeros((1, 40000), dtype=torch.int64).cuda()], [100]) is None
+
+
 def test_transposed_index_too_large_is_declined(pn2):
     idx = pn2.torch.zeros((1, 40000), dtype=pn2.torch.int64).cuda()
     assert pn2.ops.invert_index(idx, 100) is None
