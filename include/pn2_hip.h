@@ -126,6 +126,10 @@ int pn2_group_points(const float *xyz, const float *new_xyz, const float *points
  * dist3 (nullable) the expansion-form distances, weight3[B,N,3]. */
 int pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int64_t *idx3, float *dist3,
                  float *weight3, pn2_stream_t stream);
+/* n <= 8 (queries, sources) pairs of one batch size in one launch (host arrays of device pointers / sizes, read before
+ * return; no dist3). */
+int pn2_three_nn_many(int n, const float *const *xyz1, const float *const *xyz2, int B, const int *N, const int *S,
+                      int64_t *const *idx3, float *const *weight3, pn2_stream_t stream);
 
 /* interpolated[b,i,:] = sum_k points2[b,idx3[b,i,k],:] * weight3[b,i,k]
  *                                                       models/pointnet2_utils.py:303 */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "pn2_bn_bwd_finalize": [_vp, _ci, _ci, _cd, _vp, _vp, _vp, _vp, _vp],
     "pn2_copy_pad_cols": [_vp, _ci, _ci, _vp, _ci, _ci, _cl, _vp],
     "pn2_invert_index": [_vp, _ci, _cl, _ci, _vp, _vp, _vp],
+    "pn2_three_nn_many": [_ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_invert_index_many": [_ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "pn2_gather_sum": [_vp, _cl, _ci, _ci, _vp, _vp, _vp, _cl, _ci, _ci, _ci, _ci, _vp, _vp],
     "pn2_gather_sum_add": [_vp, _cl, _ci, _ci, _vp, _vp, _vp, _cl, _ci, _ci, _ci, _ci, _vp, _vp, _vp],

@@ -14,6 +14,11 @@ from . import pointnet2_utils as _utils
 from .pointnet2_utils import PointNetFeaturePropagation, PointNetSetAbstraction
 
 _INVERT_GROUPING = os.environ.get("PN2_INVERT_GROUPING", "0") == "1"
+# PN2_GEOMETRY_MERGED_LAUNCHES=1: the four interpolation levels' 3-NN tables and their transposed tables as ONE launch each
+# (2: the transposed tables only, 3: the 3-NN tables only).  Measured on one box, 60 steps, twice each: 2.534 ms per level
+# (default), transposed tables merged 2.533-2.539, 3-NN merged 2.545, both 2.551 -- a shorter geometry chain buys nothing
+# (it has slack) and one bigger launch beside the main branch costs it more than four small ones.
+_MERGED_LAUNCHES = os.environ.get("PN2_GEOMETRY_MERGED_LAUNCHES", "0")
 # the head's dropout inside the conv2 kernels (PN2_FUSED_DROPOUT=0: torch's F.dropout in front of them, for A/B runs)
 _FUSED_DROPOUT = os.environ.get("PN2_FUSED_DROPOUT", "1") == "1"
 # gradients of a level's features (grouping of the next level + skip connection) summed inside the grouping backward
@@ -80,14 +85,16 @@ class get_model(nn.Module):
             inv += list(pair) if pair is not None else [None, None]
             levels.append(new_xyz)
         idx3s = []
-        for lvl in (3, 2, 1, 0):
-            idx3, w3 = ops.three_nn(levels[lvl], levels[lvl + 1])
+        # the four levels' nearest-neighbour tables in one launch (they need the levels' coordinates and nothing else)
+        nn = ops.three_nn_many([(levels[lvl], levels[lvl + 1]) for lvl in (3, 2, 1, 0)]) if (levels[0].is_cuda and _MERGED_LAUNCHES in ("1", "3")) else \
+            [ops.three_nn(levels[lvl], levels[lvl + 1]) for lvl in (3, 2, 1, 0)]
+        for idx3, w3 in nn:
             out += [idx3, w3]
             idx3s.append(idx3)
         if for_backward:
             # the four transposed tables in one launch (one workgroup per block each: in a row they only add up latencies)
             keys = [levels[lvl + 1].shape[1] for lvl in (3, 2, 1, 0)]
-            pairs = ops.invert_index_many(idx3s, keys) if idx3s[0].is_cuda else None
+            pairs = ops.invert_index_many(idx3s, keys) if (idx3s[0].is_cuda and _MERGED_LAUNCHES in ("1", "2")) else None
             if pairs is None:
                 pairs = [ops.invert_index(i3, k) for i3, k in zip(idx3s, keys)]
             for pair in pairs:

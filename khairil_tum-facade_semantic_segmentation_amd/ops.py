@@ -505,6 +505,29 @@ def three_nn(xyz1, xyz2, want_dist=False):
     return (idx3, w3, d3) if want_dist else (idx3, w3)
 
 
+def three_nn_many(pairs):
+    """three_nn of several (xyz1 [B,N,3], xyz2 [B,S,3]) pairs of one batch size in ONE launch -> [(idx3, weight3), ...]."""
+    import ctypes
+    if not pairs:
+        return []
+    dev = _dev(*[t for p in pairs for t in p])
+    lib = _lib.load()
+    pairs = [(_f32c(a), _f32c(b)) for a, b in pairs]
+    B = pairs[0][0].shape[0]
+    n = len(pairs)
+    if n > 8 or any(a.shape[0] != B or b.shape[0] != B for a, b in pairs):
+        return [three_nn(a, b) for a, b in pairs]
+    idx3 = [torch.empty((B, a.shape[1], 3), dtype=torch.int64, device=dev) for a, _ in pairs]
+    w3 = [torch.empty((B, a.shape[1], 3), dtype=torch.float32, device=dev) for a, _ in pairs]
+    vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+    with torch.cuda.device(dev):
+        rc = lib.pn2_three_nn_many(n, vp(*[a.data_ptr() for a, _ in pairs]), vp(*[b.data_ptr() for _, b in pairs]), B,
+                                   ci(*[a.shape[1] for a, _ in pairs]), ci(*[b.shape[1] for _, b in pairs]),
+                                   vp(*[t.data_ptr() for t in idx3]), vp(*[t.data_ptr() for t in w3]), _stream(dev))
+    _lib.check(rc, "pn2_three_nn_many")
+    return list(zip(idx3, w3))
+
+
 class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points2, idx3, weight3, inv_off=None, inv_ent=None):

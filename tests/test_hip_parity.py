@@ -290,6 +290,20 @@ def test_transposed_index_backward_matches_scatter_add(pn2, orc, B, N, S, K, D):
     pn2.ops._ERR.clear()
 
 
+def test_three_nn_pairs_in_one_launch(pn2):
+    """pn2_three_nn_many: the four interpolation levels in one launch = the levels one by one (indices and weights)."""
+    torch = pn2.torch
+    rs = np.random.RandomState(21)
+    pairs = []
+    for n, s_ in ((64, 16), (256, 64), (1000, 250), (4096, 1024)):
+        pairs.append((torch.from_numpy(rs.uniform(0, 1, size=(5, n, 3)).astype(np.float32)).cuda(),
+                      torch.from_numpy(rs.uniform(0, 1, size=(5, s_, 3)).astype(np.float32)).cuda()))
+    many = pn2.ops.three_nn_many(pairs)
+    for (a, b), (i3, w3) in zip(pairs, many):
+        j3, v3 = pn2.ops.three_nn(a, b)
+        assert torch.equal(i3, j3) and torch.equal(w3, v3)
+
+
 def test_transposed_tables_in_one_launch(pn2):
     """pn2_invert_index_many: several tables of one batch size in one launch = the tables one by one."""
     torch = pn2.torch
