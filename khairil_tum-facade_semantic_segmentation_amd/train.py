@@ -337,8 +337,10 @@ class SemSegTrainer:
         placeable = dtype == torch.float32 and len(shape) == 4
         if placeable:
             ops.place_next_grouped(view)
-        geo = self._geometry_of(self._static_next_x)
-        ops.place_next_grouped(None)
+        try:
+            geo = self._geometry_of(self._static_next_x)
+        finally:
+            ops.place_next_grouped(None)                    # an offer nobody took must not reach an unrelated call
         if placeable and geo[big] is not None and geo[big].data_ptr() == view.data_ptr():
             if big > 0:
                 flat[:o0].copy_(pack_segments(geo[:big], self._geo_pads[:big]))
