@@ -204,12 +204,14 @@ def run_drop_in(args, dev):
     ops.check_errors()
     assert torch.isfinite(loss).item()
     pts = PER_GPU_BATCH * BLOCK_POINTS * args.steps
+    from khairil_tum_facade_semantic_segmentation_amd import graphed
     return {"metric": "points/sec fwd+bwd, 4096-pt blocks, pointnet2_sem_seg (drop-in mode: the reference's wiring on the HIP pointnet2_utils)",
+            "module_graphs": dict(graphed.stats, enabled=graphed.ENABLED),
             "value": pts / dt, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "switches": active_switches(),
             "config": {"workload": "pointnet2_sem_seg fwd+bwd+Adam through tests/dropin_wiring.py (channel-first module calls, torch head / "
-                                   "nll_loss / Adam, eager), batch=16x4096x%d synthetic %s blocks (BASELINE configs[1])" % (CHANNELS, args.kind),
+                                   "nll_loss / Adam; the modules replay their own captured graphs unless PN2_MODULE_GRAPHS=0), batch=16x4096x%d synthetic %s blocks (BASELINE configs[1])" % (CHANNELS, args.kind),
                        "global_batch": PER_GPU_BATCH, "points_per_block": BLOCK_POINTS, "parallelism": "dp1"}}
 
 

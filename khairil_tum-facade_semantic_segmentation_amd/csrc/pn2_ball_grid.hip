@@ -367,7 +367,9 @@ int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *
                            int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
                            hipStream_t stream)
 {
-    if (N > GR_MAXN || N < 1 || K > 64 || K < 1) return PN2_ERR_UNSUPPORTED;
+    // N >= 2: the coordinate gather is one 16-byte load per point, shifted back by a float for the block's LAST point
+    // (line "shift"); a one-point block has only 12 bytes, and for b == 0 the shifted load would start at xyz[-1]
+    if (N > GR_MAXN || N < 2 || K > 64 || K < 1) return PN2_ERR_UNSUPPORTED;
     if (grouped && !(ldg == 3 + D && ((3 + D) & 3) == 0 && (reinterpret_cast<uintptr_t>(grouped) & 15) == 0))
         return PN2_ERR_UNSUPPORTED;
     if (grouped && D > 0 && !points) return PN2_ERR_NULL;

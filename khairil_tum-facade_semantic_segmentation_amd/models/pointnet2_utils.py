@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 import os
 
-from .. import mlp, ops
+from .. import graphed, mlp, ops
 
 _FPS_START_QUEUE = []
 
@@ -234,6 +234,19 @@ def _pointwise_mlp(x, convs, bns):
     return x
 
 
+def _before_replay(module):
+    """Host-side state a captured stack reads through device memory, refreshed as the eager call would: the BatchNorm
+    momentum words (the reference loop resets `momentum` every epoch, localfunctions.py:191-195) and, in eval mode, the
+    cached scale / shift of the running statistics; a training pass rewrites those statistics behind torch's back."""
+    for bn in module.mlp_bns:
+        if bn.weight is not None:
+            mlp.momentum_word(bn, bn.weight.device)
+    if module.training:
+        mlp.invalidate_eval_coefficients()
+    else:
+        mlp.refresh_eval_coefficients(module)
+
+
 class PointNetSetAbstraction(nn.Module):                # reference :161-202
     def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
         super().__init__()
@@ -295,12 +308,24 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
             return new_xyz, y.reshape(B, S, -1), alias
         return new_xyz, y.reshape(B, S, -1)
 
+    def _forward_rows(self, xyz, points, start):
+        """The module's work on the caller's channel-first tensors, channel-last results: what a graph replays."""
+        return self.forward_cl(xyz.permute(0, 2, 1), None if points is None else points.permute(0, 2, 1), start=start)
+
     def forward(self, xyz, points):
         """xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
+        ahead = _AHEAD_ON and xyz.is_cuda and not self.group_all
+        if not ahead and not self.group_all and not _TORCH_MLP and graphed.usable(xyz, points):
+            # repeated calls of one signature replay a captured forward / backward (graphed.py).  The FPS start indices are
+            # an input of the graph, drawn here exactly as the eager path draws them (reference :75)
+            start = _next_start(xyz.device)
+            if start is None:
+                start = torch.randint(0, xyz.shape[2], (xyz.shape[0],), dtype=torch.long, device=xyz.device)
+            new_xyz, feats = graphed.call(self, self._forward_rows, (xyz, points, start), lambda: _before_replay(self))
+            return new_xyz.permute(0, 2, 1), feats.permute(0, 2, 1)
         xyz_cl = xyz.permute(0, 2, 1)
         points_cl = None if points is None else points.permute(0, 2, 1)
         geometry = None
-        ahead = _AHEAD_ON and xyz.is_cuda and not self.group_all
         if ahead:
             xyz_cl = xyz_cl.to(torch.float32).contiguous()
             key = _cf_key(xyz)
@@ -381,8 +406,15 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
             y = _mlp(points1.reshape(B * N, -1), interpolated.reshape(B * N, D2), convs, bns)
         return y.reshape(B, N, -1)
 
+    def _forward_rows(self, xyz1, xyz2, points1, points2):
+        return (self.forward_cl(xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1),
+                                None if points1 is None else points1.permute(0, 2, 1), points2.permute(0, 2, 1)),)
+
     def forward(self, xyz1, xyz2, points1, points2):
         """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N]|None, points2 [B,D2,S] -> [B,D',N]."""
+        if not _AHEAD_ON and not _TORCH_MLP and graphed.usable(xyz1, xyz2, points1, points2):
+            (y,) = graphed.call(self, self._forward_rows, (xyz1, xyz2, points1, points2), lambda: _before_replay(self))
+            return y.permute(0, 2, 1)
         nn, x1 = None, xyz1.permute(0, 2, 1)
         if _AHEAD_ON and xyz1.is_cuda:
             k1, k2 = _cf_key(xyz1), _cf_key(xyz2)

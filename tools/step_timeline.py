@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Timeline of ONE steady-state training step from a rocprofv3 --kernel-trace CSV of bench.py:
-    python tools/step_timeline.py <dir with *_kernel_trace.csv> [step_from_end]
+    python tools/step_timeline.py <dir with *_kernel_trace.csv> [step_from_end] [delimiter regex] [start|end]
 Per queue: every dispatch with its start offset, duration and the gap since the previous dispatch on that queue ended;
-then the sums (busy, gaps) per queue and per kernel name.  The step is delimited by the Adam update launches (adam_step*)."""
+then the sums (busy, gaps) per queue and per kernel name.  The step is delimited by the Adam update launches (adam_step*:
+the window runs from one's END to the next one's END) or by another kernel that occurs once per step (drop-in mode with
+torch's optimizer: the 4096-point FPS launch, 'fps_kernel<512' start: from one's START to the next one's START)."""
 import collections
 import csv
 import glob
@@ -15,11 +17,13 @@ if not files:
 rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-ends = [i for i, r in enumerate(rows) if 'adam_step' in r['Kernel_Name']]
+delim = re.compile(sys.argv[3] if len(sys.argv) > 3 else 'adam_step')
+edge = 'Start_Timestamp' if len(sys.argv) > 4 and sys.argv[4] == 'start' else 'End_Timestamp'
+ends = [i for i, r in enumerate(rows) if delim.search(r['Kernel_Name'])]
 if len(ends) < back + 1:
     sys.exit("fewer than %d steps in the trace" % (back + 1))
-t0 = int(rows[ends[-back - 1]]['End_Timestamp'])
-t1 = int(rows[ends[-back]]['End_Timestamp'])
+t0 = int(rows[ends[-back - 1]][edge])
+t1 = int(rows[ends[-back]][edge])
 sel = [r for r in rows if t0 <= int(r['Start_Timestamp']) < t1]
 qkey = 'Queue_Id' if 'Queue_Id' in rows[0] else 'Stream_Id'
 
