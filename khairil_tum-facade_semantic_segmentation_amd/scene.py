@@ -482,9 +482,9 @@ class BlockInferencer:
     the laid-out input) is computed on a parallel branch of the same graph and handed over with one copy -- the scheme of
     train.SemSegTrainer, forward only.  BatchNorm is frozen (eval), so blocks are independent: a short last sub-batch is
     padded with copies of its last block.  The graph reads the weights through the pointers they had at capture and the
-    eval-mode BatchNorm coefficients from the tensors cached on the modules: after further training call
-    mlp.refresh_eval_coefficients(model) (train.eval_epoch does) and the replays see the new values; if the parameters
-    were re-homed since (train.FlatAdam moves them into one flat buffer when a trainer is created), run() notices and
+    eval-mode BatchNorm coefficients from the tensors cached on the modules: run() refreshes those in place from the
+    current weights and running statistics first (mlp.refresh_eval_coefficients), so an engine kept across further
+    training replays the trained model; if the parameters were re-homed since (train.FlatAdam moves them into one flat buffer when a trainer is created), run() notices and
     captures again."""
 
     def __init__(self, model, batch_size, channels, num_point):
@@ -611,6 +611,11 @@ class BlockInferencer:
                 self._graph = None                                # the parameters live elsewhere now: the graph reads stale memory
             if self._graph is None:
                 self._capture()
+            # the captured forwards read the eval-mode BatchNorm scale / shift from the tensors cached on the modules; if the
+            # model was trained since they were computed they are recomputed here, in place (a key compare per BatchNorm when
+            # nothing changed) -- an engine kept across training would otherwise mix new weights with stale coefficients
+            from . import mlp
+            mlp.refresh_eval_coefficients(self.model)
             two = self._two
             main = torch.cuda.current_stream()
             if two is not None:

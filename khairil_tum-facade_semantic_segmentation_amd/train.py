@@ -137,6 +137,53 @@ class FlatAdam:
         a device scalar, so captured graphs pick it up."""
         self.lr.fill_(float(lr))
 
+    def state_dict(self):
+        """torch.optim.Adam's layout (what the reference stores as 'optimizer_state_dict', localfunctions.py:229-239,
+        315-321): per parameter index {'step', 'exp_avg', 'exp_avg_sq'} -- copies, in the parameters' own shapes -- and one
+        param_group with the hyper-parameters.  A checkpoint written here loads into torch.optim.Adam and back."""
+        step = float(self.state[0].item())
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            if step > 0:
+                state[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[off:off + k].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p).clone()}
+            off += k
+        group = {"lr": float(self.lr.item()), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """The inverse: moments and step count from a torch.optim.Adam state dict over the same parameters in the same
+        order (a parameter without state -- never stepped -- gets zeros).  In place: captured graphs keep reading the
+        same buffers."""
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(self.params):
+            raise ValueError("optimizer state for %d parameters, this optimizer has %d" % (len(ids), len(self.params)))
+        steps, off = [], 0
+        with torch.no_grad():
+            for pid, p in zip(ids, self.params):
+                k = p.numel()
+                st = sd["state"].get(pid)
+                if st is None:
+                    self.exp_avg[off:off + k].zero_()
+                    self.exp_avg_sq[off:off + k].zero_()
+                else:
+                    if st["exp_avg"].numel() != k:
+                        raise ValueError("optimizer state %d has %d elements, the parameter %d" % (pid, st["exp_avg"].numel(), k))
+                    self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.append(float(st["step"]))
+                off += k
+            if steps and min(steps) != max(steps):
+                raise ValueError("parameters were stepped %g .. %g times: one flat pass has one step count" % (min(steps), max(steps)))
+            self.state.zero_()
+            self.state[0] = steps[0] if steps else 0.0       # the kernel derives the bias corrections from the count
+            self.lr.fill_(float(groups[0]["lr"]))
+        self.betas, self.eps, self.weight_decay = tuple(groups[0]["betas"]), groups[0]["eps"], groups[0]["weight_decay"]
+
     def step_scattered(self, grads, grad_scale=1.0):
         """The update with the gradients where backward left them (one tensor or None per parameter, in the order of
         `params`): no packing pass.  False when the library does not take this many tensors (pack and use step())."""
@@ -631,7 +678,7 @@ def draw_batch(samplers, batch_size, seed, epoch, step, rank=0):
         import numpy as np
         counts, seeds = batch_plan(samplers.sizes, batch_size, seed, epoch, step, rank)
         f, l, info = samplers.sample(np.repeat(np.arange(len(counts)), counts), seeds[0])
-        _LAST_DRAW_INFO[0] = info
+        _log_draw(samplers, info)
         return f.permute(0, 2, 1), l
     counts, seeds = batch_plan([sp.P for sp in samplers], batch_size, seed, epoch, step, rank)
     feats, labels, infos = [], [], []
@@ -643,14 +690,30 @@ def draw_batch(samplers, batch_size, seed, epoch, step, rank=0):
             infos.append(info)
     f = feats[0] if len(feats) == 1 else torch.cat(feats)
     l = labels[0] if len(labels) == 1 else torch.cat(labels)
-    _LAST_DRAW_INFO[0] = infos[0] if len(infos) == 1 else torch.cat(infos)
+    _log_draw(samplers[0], infos[0] if len(infos) == 1 else torch.cat(infos))
     return f.permute(0, 2, 1), l
 
 
-# info rows [centre, population, attempts, gave-up] of the most recent draw: train_epoch looks at the last batch's once per
-# epoch (it syncs with the host there anyway).  A block whose column never reached the reference's > 1024 points within 256
-# attempts comes back as zeros with the flag set -- the reference's loop would spin forever on such a room.
-_LAST_DRAW_INFO = [None]
+def _log_draw(owner, info):
+    """info rows [centre, population, attempts, gave-up] of EVERY draw since the owner's log was last cleared, kept on the
+    sampler object (a few hundred bytes per batch, no launch, no host sync): train_epoch reads them once, at the epoch's
+    end, where it syncs with the host anyway.  A block whose column never reached the reference's > 1024 points within
+    256 attempts comes back as zeros with the flag set -- the reference's loop would spin forever on such a room -- and
+    must not be trained on silently, whichever batch of the epoch it was in."""
+    log = owner.__dict__.setdefault("draw_log", [])
+    log.append(info)
+    if len(log) > 65536:                                   # nobody is reading: keep the newest
+        del log[:32768]
+
+
+def gave_up_blocks(samplers, clear=True):
+    """Number of blocks the sampler gave up on since the log was last cleared (one host sync)."""
+    owner = samplers if hasattr(samplers, "table") else samplers[0]
+    log = owner.__dict__.get("draw_log") or []
+    n = int(torch.cat([i[:, 3] for i in log]).sum().item()) if log else 0
+    if clear:
+        del log[:]
+    return n
 
 
 def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_rate=1e-3, lr_decay=0.7, step_size=10, rank=None):
@@ -674,6 +737,7 @@ def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_ra
     if not hasattr(samplers, "table") and len(samplers) > 1 and samplers[0].dev.type == "cuda":
         from .scene import MultiRoomSampler
         samplers = MultiRoomSampler(samplers)                  # one launch per batch instead of one per contributing room
+    gave_up_blocks(samplers)                               # a fresh log for this epoch
     nxt = draw_batch(samplers, batch_size, seed, epoch, 0, rank)
     loss_sum = None
     for i in range(steps):
@@ -682,10 +746,11 @@ def train_epoch(trainer, samplers, epoch, steps, batch_size, seed=0, learning_ra
         loss_sum = loss.clone() if loss_sum is None else loss_sum + loss
     trainer.drop_prefetched()                              # the last batch was announced as its own successor
     out = {"loss": float(loss_sum) / max(steps, 1), "lr": lr, "bn_momentum": momentum}
-    if _LAST_DRAW_INFO[0] is not None and bool(_LAST_DRAW_INFO[0][:, 3].any()):
-        raise RuntimeError("the block sampler gave up on %d block(s) of the epoch's last batch: no 1 m column with more than 1024 "
+    gave_up = gave_up_blocks(samplers)
+    if gave_up:
+        raise RuntimeError("the block sampler gave up on %d block(s) of this epoch: no 1 m column with more than 1024 "
                            "points was found in 256 attempts (a room that sparse makes the reference's sampling loop spin "
-                           "forever, sem_seg_training.py:207-216)" % int(_LAST_DRAW_INFO[0][:, 3].sum()))
+                           "forever, sem_seg_training.py:207-216)" % gave_up)
     if trainer.metrics is not None:
         out.update(trainer.metrics.read())
     return out
@@ -709,20 +774,53 @@ def label_weights(labels_per_room, num_classes, device=None):
 
 
 class BestModel:
-    """The reference's checkpoint rule (localfunctions.py:310-322): keep the state whenever the evaluation mIoU is at
-    least the best so far."""
+    """The reference's best-model rule (localfunctions.py:310-322): keep the state whenever the evaluation mIoU is at
+    least the best so far -- in memory, and as the reference's `best_model.pth` when `path` is given (save_checkpoint)."""
 
-    def __init__(self):
+    def __init__(self, path=None):
         self.best_iou = 0.0
         self.epoch = None
         self.state = None
+        self.path = path
 
-    def update(self, epoch, miou, model):
+    def update(self, epoch, miou, model, optimizer=None):
         if miou >= self.best_iou:
             self.best_iou, self.epoch = float(miou), epoch
             self.state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            if self.path is not None:
+                save_checkpoint(self.path, epoch, model, optimizer, class_avg_iou=miou)
             return True
         return False
+
+
+def save_checkpoint(path, epoch, model, optimizer=None, class_avg_iou=None):
+    """The reference's checkpoint files (localfunctions.py:229-239 `model.pth` every fifth epoch; :310-322 `best_model.pth`
+    with 'class_avg_iou'): {'epoch', ['class_avg_iou',] 'model_state_dict', 'optimizer_state_dict'} through torch.save.
+    The model's keys are the reference's (same submodule names), so sem_seg_testing.py:496-497 loads the file as it is;
+    optimizer = a SemSegTrainer, a FlatAdam or a torch optimizer."""
+    opt = getattr(optimizer, "flat_adam", None) or getattr(optimizer, "optimizer", None) or optimizer
+    state = {"epoch": int(epoch), "model_state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}
+    if class_avg_iou is not None:
+        state["class_avg_iou"] = float(class_avg_iou)
+    if opt is not None:
+        osd = opt.state_dict()
+        state["optimizer_state_dict"] = {"state": {i: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                                   for i, st in osd["state"].items()}, "param_groups": osd["param_groups"]}
+    torch.save(state, path)
+    return state
+
+
+def load_checkpoint(path, model, optimizer=None):
+    """Resume from a checkpoint of save_checkpoint() or of the reference loop (sem_seg_training.py:567-570 reads 'epoch' and
+    'model_state_dict'): parameters and buffers are copied IN PLACE (captured graphs stay valid), optimizer moments too.
+    -> the checkpoint dict (its 'epoch' is where the reference resumes)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["model_state_dict"])
+    mlp.invalidate_eval_coefficients()
+    opt = getattr(optimizer, "flat_adam", None) or getattr(optimizer, "optimizer", None) or optimizer
+    if opt is not None and "optimizer_state_dict" in ck:
+        opt.load_state_dict(ck["optimizer_state_dict"])
+    return ck
 
 
 def eval_epoch(model, batches, class_weight=None, batch_size=None, engine=None, metrics=None):

@@ -103,3 +103,39 @@ def test_block_inferencer_matches_eager_forward(orc, synth, monkeypatch):
     a = scene.infer_scene(model, data, idx, wt, P, K, batch_size=4)
     b = scene.infer_scene(model, data, idx, wt, P, K, batch_size=4, graphs=True)
     assert torch.equal(a, b)
+
+
+def test_block_inferencer_kept_across_training_sees_the_trained_model(orc, synth, monkeypatch):
+    """An engine captured before further training (the docstring recommends keeping one per model across scenes) replays the
+    TRAINED model: run() refreshes the cached eval-mode BatchNorm coefficients in place.  Training moves weights (torch
+    Adam: version counters bump) and running statistics (raw kernels: no version bump) -- both must arrive."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd import scene
+    from khairil_tum_facade_semantic_segmentation_amd.models import pointnet2_sem_seg as M
+    real_randint = torch.randint
+    monkeypatch.setattr(torch, "randint", lambda low, high, size, **kw: real_randint(0, 1, size, **kw))   # FPS starts
+    K, B, N = 8, 2, 2048
+    dev = torch.device("cuda:0")
+    model = M.get_model(K, 3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(orc.state_shapes(K, 3)).items()})
+    model = model.to(dev).eval()
+    blocks, labels, _, _ = synth.draw_case(411, B, N, 9, "cube", K)
+    x = torch.from_numpy(np.ascontiguousarray(blocks.transpose(0, 2, 1))).to(dev)
+    y = torch.from_numpy(labels).to(dev).view(-1)
+    engine = scene.BlockInferencer(model, B, 9, N)
+    first = []
+    engine.run([x], lambda i, logp: first.append(logp.clone()))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad()
+        logp, tf = model(x)
+        M.get_loss()(logp.reshape(-1, K), y, tf, None).backward()
+        opt.step()
+    model.eval()
+    got = []
+    engine.run([x], lambda i, logp: got.append(logp.clone()))     # BEFORE any eager eval forward could refresh the cache
+    with torch.no_grad():
+        want = model(x)[0].clone()
+    assert not torch.equal(want, first[0])                 # the model did move
+    assert torch.equal(got[0], want)
