@@ -52,6 +52,31 @@ __device__ __forceinline__ float wave_max_f(float v)
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// max over the 64 lanes with the DPP operand fused into v_max_f32 (the builtin form canonicalises both operands of every
+// fmaxf: three instructions a step); IEEE maxNum: a NaN lane is ignored.  Result uniform.
+__device__ __forceinline__ float wave_max_f_dpp(float v)
+{
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// SAMPLED = false: the grid spans the bounding box of the block's points (a workgroup-wide reduction of eight quantities).
+// SAMPLED = true (round 4): no block-wide reduction.  ANY box gives a correct grid -- cell_of() clamps, the clamp is
+// monotone, and two points at most one cell width apart land at most one cell apart wherever the box sits -- so the box
+// is that of the block's first 64 centroids (farthest point sampling picks the extremes first: it is nearly the block's),
+// reduced inside each wave, identically in all of them.  The rounding slack of the reference's distance expression comes
+// from each centroid's own norm instead of the block's largest: a pair the reference accepts has true distance t with
+// t^2 <= r^2 + 2^-19 (|c| + t)^2, hence t <= R'_c = sqrt(r^2 + 2^-19 (|c| + 2r)^2) whenever R'_c <= 2r; a centroid whose
+// R'_c exceeds the cell width (or 2r, or is not finite) tests every point, and so does the whole workgroup when the block
+// holds a non-finite coordinate (a flag in LDS).
+template <bool SAMPLED>
 __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ points,
     int B, int N, int S, int K, int D, int ldg, float r2, int tiles_per_block, unsigned ldg_magic,
@@ -113,9 +138,34 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
         uint4 *z4 = reinterpret_cast<uint4 *>(bm);
         for (int i = tid; i < GR_CENT * GR_BMW / 4; i += GR_THREADS) z4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    // bounding box (as maxima of +-coordinate), largest squared norm, non-finite flag
     float pn[GR_PT];
-    float q[8] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, cn, (cn < INFINITY) ? 0.0f : 1.0f};
+    float q[8];
+    if (SAMPLED) {
+        // this lane's sample: centroid `lane` of the block (loaded before the barrier: its latency hides behind the zeroing)
+        const int sl = lane < S ? lane : S - 1;
+        const float sx = bc[sl * 3 + 0], sy = bc[sl * 3 + 1], sz = bc[sl * 3 + 2];
+        if (tid == 0) red[0] = 0.0f;                       // the block's "a coordinate is not finite" flag (the box scratch is free)
+        __syncthreads();                                   // zeroed histogram / bitmaps / flag before anybody adds to them
+        PN2_STAMP(2);
+        q[0] = wave_max_f_dpp(-sx); q[1] = wave_max_f_dpp(-sy); q[2] = wave_max_f_dpp(-sz);
+        q[3] = wave_max_f_dpp(sx);  q[4] = wave_max_f_dpp(sy);  q[5] = wave_max_f_dpp(sz);
+        const float sn = pn2::norm3(sx, sy, sz);
+        q[6] = wave_max_f_dpp(sn);
+        // a sample that is not finite: v_max ignored its NaNs, an infinity shows in the extent below
+        q[7] = 0.0f;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < GR_PT; ++i) {
+            pn[i] = pn2::norm3(px[i], py[i], pz[i]);
+            bad |= pj[i] < N && !(pn[i] < INFINITY);
+        }
+        if (bad) *reinterpret_cast<volatile float *>(red) = 1.0f;
+        PN2_STAMP(3);
+    } else {
+    // bounding box (as maxima of +-coordinate), largest squared norm, non-finite flag
+    q[0] = q[1] = q[2] = q[3] = q[4] = q[5] = -INFINITY;
+    q[6] = cn;
+    q[7] = (cn < INFINITY) ? 0.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < GR_PT; ++i) {
         pn[i] = pn2::norm3(px[i], py[i], pz[i]);
@@ -147,18 +197,34 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
             q[4 + k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vb), 16 * k));
         }
     }
+    }
     const float mnx = -q[0], mny = -q[1], mnz = -q[2];
     // ---- (2) grid: cells at least R' wide.  |computed dist - true dist| <= 20 u M2 (u = 2^-24, M2 the
     //      largest squared norm: 3 roundings in the dot, 3 per norm, 2 in the sums, on values <= 4 M2);
     //      2^-19 M2 covers it, and 0.1 % on R' covers the rounding of the cell coordinates themselves.
-    const float Rp = sqrtf(r2 + q[6] * 1.9073486328125e-06f) * 1.001f;
+    // SAMPLED: (|c| + 2r)^2 <= 2 |c|^2 + 8 r^2 bounds the squared norm of anything in a sampled centroid's ball (no root)
+    const float Rp = sqrtf(r2 + (SAMPLED ? 2.0f * q[6] + 8.0f * r2 : q[6]) * 1.9073486328125e-06f) * 1.001f;
     int Gx = 1, Gy = 1, Gz = 1;
     float ihx = 0.0f, ihy = 0.0f, ihz = 0.0f;
     const float ex = q[3] - mnx, ey = q[4] - mny, ez = q[5] - mnz;
+    float hmin2 = INFINITY;                                // SAMPLED: square of the narrowest cell (an axis with one cell constrains nothing)
     if (q[7] == 0.0f && Rp > 0.0f && Rp < INFINITY) {
-        if (ex > 0.0f) { Gx = (int)fminf(fmaxf(floorf(ex / Rp), 1.0f), (float)GR_GMAX); ihx = (float)Gx / ex; }
-        if (ey > 0.0f) { Gy = (int)fminf(fmaxf(floorf(ey / Rp), 1.0f), (float)GR_GMAX); ihy = (float)Gy / ey; }
-        if (ez > 0.0f) { Gz = (int)fminf(fmaxf(floorf(ez / Rp), 1.0f), (float)GR_GMAX); ihz = (float)Gz / ez; }
+        if (SAMPLED) {
+            // hardware reciprocals (1 ulp) behind a 2^-10 safety factor: G <= ex / R' holds, and the cell width 1 / ih the
+            // binning uses differs from ex / G by ulps, inside the 0.1 % already on R'
+            const float iR = __builtin_amdgcn_rcpf(Rp) * 0.9990234375f;
+            if (ex > 0.0f) { Gx = (int)fminf(fmaxf(floorf(ex * iR), 1.0f), (float)GR_GMAX); ihx = (float)Gx * __builtin_amdgcn_rcpf(ex); }
+            if (ey > 0.0f) { Gy = (int)fminf(fmaxf(floorf(ey * iR), 1.0f), (float)GR_GMAX); ihy = (float)Gy * __builtin_amdgcn_rcpf(ey); }
+            if (ez > 0.0f) { Gz = (int)fminf(fmaxf(floorf(ez * iR), 1.0f), (float)GR_GMAX); ihz = (float)Gz * __builtin_amdgcn_rcpf(ez); }
+            const float wx = ex * __builtin_amdgcn_rcpf((float)Gx), wy = ey * __builtin_amdgcn_rcpf((float)Gy), wz = ez * __builtin_amdgcn_rcpf((float)Gz);
+            if (Gx > 1) hmin2 = fminf(hmin2, wx * wx);
+            if (Gy > 1) hmin2 = fminf(hmin2, wy * wy);
+            if (Gz > 1) hmin2 = fminf(hmin2, wz * wz);
+        } else {
+            if (ex > 0.0f) { Gx = (int)fminf(fmaxf(floorf(ex / Rp), 1.0f), (float)GR_GMAX); ihx = (float)Gx / ex; }
+            if (ey > 0.0f) { Gy = (int)fminf(fmaxf(floorf(ey / Rp), 1.0f), (float)GR_GMAX); ihy = (float)Gy / ey; }
+            if (ez > 0.0f) { Gz = (int)fminf(fmaxf(floorf(ez / Rp), 1.0f), (float)GR_GMAX); ihz = (float)Gz / ez; }
+        }
     }
     auto cell_of = [&](float x, float y, float z, int &ix, int &iy, int &iz) {
         ix = min(Gx - 1, max(0, (int)((x - mnx) * ihx)));
@@ -250,11 +316,20 @@ __global__ __launch_bounds__(GR_THREADS) void ball_query_group_grid_kernel(
                 cum[dz * 3 + dy] = tot;
             }
         }
+        bool all = false;
+        if (SAMPLED) {
+            // this centroid's own rounding slack ((|c| + 2r)^2 <= 2 |c|^2 + 8 r^2) against the cell width, 0.3 % on the
+            // squares for the roundings; a non-finite coordinate anywhere in the block
+            const float Rc2 = r2 + (2.0f * cn + 8.0f * r2) * 1.9073486328125e-06f;
+            all = !(Rc2 <= 4.0f * r2) || !(Rc2 * 1.003f <= hmin2) || *reinterpret_cast<volatile float *>(red) != 0.0f;
+            tot = all ? N : tot;                               // every point of the block, in sorted order
+        }
 #pragma unroll 2
         for (int pos = l16; pos < tot; pos += 16) {
             int o = off[8];
 #pragma unroll
             for (int i = 7; i >= 0; --i) o = pos < cum[i] ? off[i] : o;
+            if (SAMPLED) o = all ? 0 : o;
             const int j = o + pos;
             const float4 p = sP[j];
             const float d = pn2::pair_sqdist(cx, cy, cz, cn, p.x, p.y, p.z, p.w);
@@ -365,7 +440,7 @@ namespace pn2 {
 // uses the matrix-core or the vector-unit kernel).
 int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
                            int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
-                           hipStream_t stream)
+                           hipStream_t stream, bool sampled_box)
 {
     // N >= 2: the coordinate gather is one 16-byte load per point, shifted back by a float for the block's LAST point
     // (line "shift"); a one-point block has only 12 bytes, and for b == 0 the shifted load would start at xyz[-1]
@@ -380,10 +455,17 @@ int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *
     if (nwg > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
     const int qpr = (3 + D) >> 2;
     const unsigned magic = qpr > 1 ? (unsigned)((1ULL << 32) / (unsigned)qpr) + 1u : 0u;     // e/qpr exact for e*qpr < 2^32
-    static pn2::PerDevice lds_memo;
-    if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(ball_query_group_grid_kernel), 160 * 1024, lds_memo)) return e;
-    hipLaunchKernelGGL(ball_query_group_grid_kernel, dim3((unsigned)nwg), dim3(GR_THREADS), lds, stream, xyz, new_xyz, points,
-                       B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count);
+    if (sampled_box) {
+        static pn2::PerDevice lds_memo;
+        if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(ball_query_group_grid_kernel<true>), 160 * 1024, lds_memo)) return e;
+        hipLaunchKernelGGL(ball_query_group_grid_kernel<true>, dim3((unsigned)nwg), dim3(GR_THREADS), lds, stream, xyz, new_xyz, points,
+                           B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count);
+    } else {
+        static pn2::PerDevice lds_memo;
+        if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(ball_query_group_grid_kernel<false>), 160 * 1024, lds_memo)) return e;
+        hipLaunchKernelGGL(ball_query_group_grid_kernel<false>, dim3((unsigned)nwg), dim3(GR_THREADS), lds, stream, xyz, new_xyz, points,
+                           B, N, S, K, D, ldg, r2, tiles, magic, idx, grouped, err_count);
+    }
     return PN2_LAUNCH_RC();
 }
 

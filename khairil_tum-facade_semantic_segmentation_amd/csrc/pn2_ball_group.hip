@@ -17,7 +17,7 @@
 namespace pn2 {
 int launch_ball_query_grid(const float *xyz, const float *new_xyz, const float *points, int B, int N, int S, int K,
                            int D, int ldg, float r2, int64_t *idx, float *grouped, int32_t *err_count,
-                           hipStream_t stream);
+                           hipStream_t stream, bool sampled_box);
 }
 
 namespace {
@@ -370,7 +370,8 @@ int launch_ball_query_group(const float *xyz, const float *new_xyz, const float 
 
 }  // namespace
 
-// which: 0 = the library's choice; 1 = cell-pruned (pn2_ball_grid.hip); 2 = the vector-unit scan of this file.
+// which: 0 = the library's choice; 1 = cell-pruned (pn2_ball_grid.hip), the grid over the block's bounding box; 3 = the same
+// with the grid over the box of the block's first 64 centroids (no workgroup-wide reduction); 2 = the vector-unit scan of this file.
 // (A matrix-core kernel -- the exact expression as a k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 -- was
 // withdrawn in round 3: at the one shape the dispatch still gave it, SA2's 1024-point blocks, the scan below is faster
 // (7.1 against 12.3 us), and its sign-bit membership test dropped NaN points, which the reference keeps.)  A kernel that does not take the operands
@@ -387,16 +388,19 @@ static int ball_query_group_dispatch(int which, double radius, int nsample, cons
     if (nsample > 64) return PN2_ERR_UNSUPPORTED;
     if (ldg == 0) ldg = 3 + D;
     if (ldg < 3 + D) return PN2_ERR_SHAPE;
-    if (which < 0 || which > 2) return PN2_ERR_UNSUPPORTED;
+    if (which < 0 || which > 3) return PN2_ERR_UNSUPPORTED;
     if (B == 0) return PN2_OK;
     const float r2 = (float)(radius * radius);          // python `radius ** 2` (double), compared in fp32
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const long long total = (long long)B * S;
     // Many centroids over a large block that fits LDS: cell-pruned candidates (pn2_ball_grid.hip).
-    if (which == 1 || (which == 0 && total >= 4096 && N >= pn2::tune_get("bq_grid_minn", 2048) && pn2::tune_get("bq_grid", 1))) {
+    if (which == 1 || which == 3 || (which == 0 && total >= 4096 && N >= pn2::tune_get("bq_grid_minn", 2048) && pn2::tune_get("bq_grid", 1))) {
+        // the library's choice: the grid over the box of the block's first centroids (no block-wide reduction: 19.4 against
+        // 19.5 us cube, 20.8 against 21.6 us facade, profiles/r04/ballbench_sampled_box.log); which = 1 keeps the round-1 form
+        const bool sampled = which == 3 || (which == 0 && pn2::tune_get("bq_grid_sampled", 1));
         const int rc = pn2::launch_ball_query_grid(xyz, new_xyz, points, B, N, S, nsample, D, ldg, r2, idx, grouped,
-                                                   err_count, stream);
-        if (rc != PN2_ERR_UNSUPPORTED || which == 1) return rc;
+                                                   err_count, stream, sampled);
+        if (rc != PN2_ERR_UNSUPPORTED || which != 0) return rc;
     }
     const int cfg = pn2::tune_get("bq_cfg", total >= 8192 ? 3 : (total >= 2048 ? 1 : 2));
     // Few centroids with wide rows (deep levels): the gather is latency-bound inside the scan
