@@ -79,8 +79,11 @@ def cpu_baseline(seconds_budget=14.0):
     dt = float(np.median(steps))
     out = {"value": PER_GPU_BATCH * BLOCK_POINTS / dt, "unit": "points/s", "cores": threads, "kind": "port",
            "cpu_model": host_cpu_model(),
-           "sample": "median of %d fwd+bwd+Adam steps of %dx%dx%d cube blocks after 1 warm-up (%.2f s each, min %.2f max %.2f), "
-                     "oracle (C index ops + torch CPU)" % (len(steps), PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt, min(steps), max(steps)),
+           "sample": "median of %d fwd+bwd+Adam steps of %dx%dx%d cube blocks after 1 warm-up (%.2f s each, min %.2f max %.2f); the "
+                     "builder's oracle: loop-form C index ops under OpenMP (FPS, ball query with early exit, grouping, 3-NN) + torch CPU "
+                     "convolutions / autograd / Adam -- NOT the reference's sort-based torch composition, whose ball query alone took "
+                     "0.4-1.0 s per call in the survey container (SURVEY.md 6): a stronger CPU baseline than the reference's own path"
+                     % (len(steps), PER_GPU_BATCH, BLOCK_POINTS, CHANNELS, dt, min(steps), max(steps)),
            "step_seconds": steps}
     # configs[0]: one 4096x9 block, one fwd+bwd(+Adam) step
     one = [s[:1] for s in starts]
@@ -244,6 +247,10 @@ def main():
                     help="time the DROP-IN mode: the reference's own wiring (tests/dropin_wiring.py: channel-first module calls, torch "
                          "head, F.nll_loss, torch.optim.Adam, eager launches) on the package's models.pointnet2_utils -- what a maintainer "
                          "gets who swaps only pointnet2_utils.py; none of the package's own fast-path wiring")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="after the K timed steps, replay the step for about this many seconds and report sustained_ms_per_step (0: skip)")
+    ap.add_argument("--batch-sweep", action="store_true",
+                    help="secondary record: the step at 32 and 64 blocks per GPU as well (the headline stays 16, BASELINE configs[1])")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute each batch's FPS/ball-query/3-NN pyramid inside its own step instead of one step ahead on a side stream")
     args = ap.parse_args()
@@ -322,6 +329,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(loss).item(), "training step produced a non-finite loss"
+    # sustained leg (outside the driver's K timed steps): the same step replayed for >= args.sustain seconds -- clocks and
+    # power settle, and a busy sampler sees the GPU working; max over ranks like the headline
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(int(args.sustain / max(dt / args.steps, 1e-4)), args.steps)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            loss = trainer.step(x, y)
+        barrier()
+        dts = time.perf_counter() - ts
+        if world > 1:
+            t = torch.tensor([dts], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3,
+                     "points_per_s": world * PER_GPU_BATCH * BLOCK_POINTS * n_sus / dts}
+        assert torch.isfinite(loss).item()
     # evidence that the collective ran over N ranks: backend, world size and the measured all-reduce of the packed gradient
     dp_info = None
     if use_dist:
@@ -339,6 +364,28 @@ def main():
         dp_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gradient_bytes": trainer.grads.numel * 4,
                    "all_reduce_us": float(t.item()), "collectives_per_step": 1}
 
+    # secondary record: larger per-GPU batches (fresh models and trainers; the 288 GB of HBM hold ~100x the headline batch)
+    sweep = None
+    if args.batch_sweep and world == 1 and not args.no_graphs:
+        sweep = {}
+        for bsz in (32, 64):
+            blk, lab, _, _ = synth.draw_case(synth.BENCH_SEED + rank, bsz, BLOCK_POINTS, step_channels, args.kind, NUM_CLASSES)
+            xb = torch.from_numpy(np.ascontiguousarray(blk.transpose(0, 2, 1))).to(dev)
+            yb = torch.from_numpy(lab).to(dev)
+            mb = M.get_model(NUM_CLASSES, step_channels - 6)
+            mb.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+            tb = SemSegTrainer(mb.to(dev), class_weight=torch.ones(NUM_CLASSES, device=dev), graphs=True, prefetch_geometry=not args.no_prefetch)
+            for _ in range(6):
+                tb.step(xb, yb)
+            torch.cuda.synchronize(dev)
+            tsw = time.perf_counter()
+            nsw = 30
+            for _ in range(nsw):
+                tb.step(xb, yb)
+            torch.cuda.synchronize(dev)
+            dsw = time.perf_counter() - tsw
+            sweep[str(bsz)] = {"ms_per_step": dsw / nsw * 1e3, "points_per_s": bsz * BLOCK_POINTS * nsw / dsw}
+            del tb, mb, xb, yb
     # roofline of the north_star kernel: SA1 query_ball_point+group at B=16, N=4096, S=1024, K=32, D=9, same resident
     # inputs as the timed steps, priced at OPERATOR level: from (xyz, new_xyz, feats) to (idx, grouped), everything a
     # caller with nothing prepared must launch = ONE call of pn2_ball_query_group (one launch of the cell-pruned
@@ -492,6 +539,11 @@ def main():
                                                     "plan_ms": prod_ms_o, "pair_frac": frac(k_ms_o + prod_ms_o)}},
                          "fps_kernel_ms": fps_plain_ms},
         }
+        if sustained is not None:
+            out["sustained_ms_per_step"] = sustained["ms_per_step"]
+            out["sustained"] = sustained
+        if sweep is not None:
+            out["batch_sweep"] = sweep
         if dp_info is not None:
             out["data_parallel"] = dp_info
         if world == 1 and not args.no_cpu_baseline:

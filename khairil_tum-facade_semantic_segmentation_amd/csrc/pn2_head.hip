@@ -36,15 +36,19 @@ __device__ __forceinline__ unsigned long long drop_seed_value(const DropArgs &d)
     }
     return d.seed ? *d.seed : 0ull;
 }
-// end of a counted forward launch (every thread of the workgroup has read the state long before: barriers lie between)
+// End of a counted forward launch.  `seed` is the value the workgroup read at its START (stage_rows received the same
+// register): that load has long completed -- its value masked every staged element -- so nothing of this workgroup still
+// reads the state when it takes its ticket, and the workgroup that takes the last one may count the call.  The counter
+// and the ticket change through device-scope atomics (no plain store races a later launch's first read: the kernel
+// boundary orders those).
 __device__ __forceinline__ void drop_count_call(const DropArgs &d, unsigned long long seed)
 {
     if (!d.state || threadIdx.x != 0) return;
     if (blockIdx.x == 0) *d.seed_out = seed;
     unsigned *ticket = reinterpret_cast<unsigned *>(d.state + 2);
     if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-        *ticket = 0u;
-        d.state[1] = d.state[1] + 1ull;
+        atomicExch(ticket, 0u);
+        atomicAdd(d.state + 1, 1ull);
     }
 }
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned row, unsigned col, unsigned thresh)
@@ -65,9 +69,8 @@ __device__ __forceinline__ float4 drop4(float4 v, const DropArgs &d, unsigned lo
 // 64 rows x K floats -> LDS tile: the (up to) 8 float4 of a thread are all loaded before the first LDS store,
 // unconditionally (clamped row, masked value): a load-store loop would wait for every load in turn.
 __device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy, int row0, int M, int k4n, float *__restrict__ sY, int tid,
-                                           const DropArgs &d)
+                                           const DropArgs &d, unsigned long long seed)
 {
-    const unsigned long long seed = drop_seed_value(d);
     constexpr int NI = HD_ROWS * (HD_KMAX / 4) / HD_THREADS;          // 8
     const int total = HD_ROWS * k4n;
     float4 v[NI];
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
         const int j = e / k4n, q = e - j * k4n;
         *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
     }
-    stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
+    const unsigned long long seed0 = drop_seed_value(drop);      // read ONCE per workgroup (see drop_count_call)
+    stage_rows(y, ldy, row0, M, k4n, sY, tid, drop, seed0);
     __syncthreads();
     const int r = tid & 63, jq = tid >> 6;
     float acc[CQ];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
         const int rr = e / C;
         o[e] = sL[rr][e - rr * C];
     }
-    if (drop.state) drop_count_call(drop, drop_seed_value(drop));
+    if (drop.state) drop_count_call(drop, seed0);
 }
 
 // K = 128 (the model's head): the 64 x C products of a tile on the matrix cores.  Wave w takes row block w & 1 and
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
         const int j = e / k4n, q = e - j * k4n;
         *reinterpret_cast<float4 *>(&sW[j * HD_LDW + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * HD_KMAX + 4 * q]);
     }
-    stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
+    const unsigned long long seed0 = drop_seed_value(drop);      // read ONCE per workgroup (see drop_count_call)
+    stage_rows(y, ldy, row0, M, k4n, sY, tid, drop, seed0);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int rb = wave & 1, kh = wave >> 1;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
         const int rr = e / C;
         o[e] = sL[rr][e - rr * C];
     }
-    if (drop.state) drop_count_call(drop, drop_seed_value(drop));
+    if (drop.state) drop_count_call(drop, seed0);
 }
 
 // ---- backward ----------------------------------------------------------------------------------------
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
                 lv[i] = lt[e];
             }
         }
-        stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
+        stage_rows(y, ldy, row0, M, k4n, sY, tid, drop, drop_seed_value(drop));
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int e = tid + i * HD_THREADS;
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
                 lv[i] = lt[e];
             }
         }
-        stage_rows(y, ldy, row0, M, k4n, sY, tid, drop);
+        stage_rows(y, ldy, row0, M, k4n, sY, tid, drop, drop_seed_value(drop));
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int e = tid + i * HD_THREADS;

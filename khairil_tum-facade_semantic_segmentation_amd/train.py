@@ -271,6 +271,7 @@ class SemSegTrainer:
         self._eager_steps = 0
         self._g_fwd_bwd = self._g_opt = self._g_geo = self._alt = None
         self._static_x = self._static_y = self._static_loss = None
+        self._tap = None                 # test hook: called with clones of the pyramid tensors a replay is about to read
 
     def broadcast_parameters(self, src=0):
         """Replicas start identical: rank `src`'s parameters and buffers go to every rank."""
@@ -530,7 +531,7 @@ class SemSegTrainer:
                 self._fill_next_pyramid(bufs[0])
             torch.cuda.current_stream().wait_stream(self._side)
             torch.cuda.synchronize()
-            self._alt = {"geo": [self._g_geo, g_geo1], "main": [None, None], "loss": [None, None], "bufs": bufs, "p": 0}
+            self._alt = {"geo": [self._g_geo, g_geo1], "main": [None, None], "loss": [None, None], "bufs": bufs, "views": views, "p": 0}
         self._g_fwd_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fwd_bwd, pool=pool):
             geo = new_geo = None
@@ -615,6 +616,9 @@ class SemSegTrainer:
             self._geo_next_src = self._identity(nxt)
             if self._g_geo is not None:
                 self._side.wait_stream(main)                    # the copies above: the second buffer and the next input are free / set
+        if self.prefetch and self._tap is not None:
+            read = self._geo_cur if self._alt is None else self._alt["views"][self._alt["p"]]
+            self._tap([None if t is None else t.clone() for t in read])     # enqueued behind the fix-ups, in front of the replay
         if self.prefetch and self._alt is not None:
             alt = self._alt
             p = alt["p"]

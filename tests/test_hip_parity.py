@@ -112,9 +112,10 @@ def test_ball_query_group_ragged_shapes(pn2, orc, B, N, S, K, D):
                                               (5, 3333, 1000, 7, 13, 0.12), (64, 64, 64, 32, 9, 0.12),
                                               (7, 4096, 640, 32, 9, 0.5), (9, 2500, 500, 8, 1, 2.0)])
 def test_ball_query_many_centroids_ragged(pn2, orc, B, N, S, K, D, radius):
-    """B*S >= 4096 through ops (which plans blocks of more than 1024 points and otherwise takes the library's
-    self-contained choice: cell-pruned kernel for N >= 2048, vector-unit scan below): ragged S / N / K, dense balls
-    (truncation), duplicates, with and without grouping.  tests/test_hip_ball_kernels.py forces every kernel by name."""
+    """B*S >= 4096 through ops WITHOUT a plan (ops never builds one on its own: a single-use plan costs more than it
+    saves): the library's self-contained choice -- the cell-pruned kernel (pn2_ball_grid.hip) for N >= 2048, the
+    vector-unit scan (pn2_ball_group.hip) below: ragged S / N / K, dense balls (truncation), duplicates, with and without
+    grouping.  tests/test_hip_ball_kernels.py forces every kernel by name."""
     rs = np.random.RandomState(B + N + S)
     xyz = rs.uniform(-0.5, 0.5, size=(B, N, 3)).astype(np.float32)
     xyz[:, :, 1] *= 0.05                                     # thin slab: many balls exceed K (and K+32) hits
@@ -456,8 +457,9 @@ def test_full_size_properties_b16(pn2, orc, synth):
 
 @pytest.mark.parametrize("case", ["offset", "huge_coords", "nan_block", "outside", "clustered", "degenerate_axis"])
 def test_ball_query_cell_pruned_path(pn2, orc, case):
-    """B*S >= 4096 and 1024 < N <= 8192: ops builds a plan and runs the binned query (pn2_ball_binned.hip); the same
-    cases go through the cell-pruned kernel (pn2_ball_grid.hip) by name in tests/test_hip_ball_kernels.py.  A candidate
+    """B*S >= 4096 and 2048 <= N <= 4096 through ops without a plan: the cell-pruned kernel (pn2_ball_grid.hip, the
+    library's choice at this shape); the planned pair (pn2_ball_binned.hip) and every other kernel run the same kind of
+    cases by name in tests/test_hip_ball_kernels.py.  A candidate
     set must never change the result: coordinates far from the origin (rounding of the reference's distance
     expression grows with |p|^2), non-finite coordinates, centroids outside the cloud's bounding box,
     dense clusters (hit-list overflow -> ordered rescan) and clouds flat in one axis."""

@@ -59,6 +59,49 @@ def test_graph_and_prefetch_steps_match_eager(monkeypatch):
         assert got[-1] < got[0], mode
 
 
+# the captured step's forms: module switches of train.py (A/B evidence in DESIGN.md 6); every one that ships is run here
+STEP_FORMS = {"two graphs": {},
+              "forked graph": {"_SEPARATE_GEOMETRY_GRAPH": False},
+              "forked graph, hand-over on the side branch": {"_SEPARATE_GEOMETRY_GRAPH": False, "_HANDOVER_ON_MAIN": False},
+              "alternating step graphs": {"_ALTERNATE_STEP_GRAPHS": True}}
+
+
+@pytest.mark.parametrize("form", sorted(STEP_FORMS))
+def test_every_replay_reads_the_pyramid_of_the_batch_it_trains_on(monkeypatch, form):
+    """Graph + prefetch on alternating cube / facade batches: the pyramid tensors a replay is about to read (cloned by a
+    hook right in front of it) equal compute_geometry() of THAT batch bit for bit -- the prefetched one when the batch was
+    announced, a freshly computed one when it was not (a step on another batch than the one announced; the same batch
+    twice in a row).  A stale or foreign pyramid cannot hide behind a loss tolerance here.  All four forms of the step."""
+    torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
+    from khairil_tum_facade_semantic_segmentation_amd import train as T
+    for k, v in STEP_FORMS[form].items():
+        monkeypatch.setattr(T, k, v)
+    model = fresh_model()
+    want = []
+    with torch.no_grad():
+        for x in xs:                                   # the pyramid is a function of the coordinates only (FPS starts pinned)
+            prepared = model.prepare_input(x, None)
+            want.append(model.compute_geometry(prepared=prepared, group_first=True) + [prepared[0], prepared[1]])
+    tr = T.SemSegTrainer(model, class_weight=cw, graphs=True, prefetch_geometry=True, graph_warmup=0)
+    taps = []
+    tr._tap = taps.append
+    # (batch trained on, batch announced as the next one)
+    plan = [(0, 1), (1, 0), (0, 1), (1, 1), (1, 0), (1, 0), (0, None), (0, 1), (1, 0)]    # 5: announced 0, trains 1; 6: no announcement
+    losses = []
+    for b, nxt in plan:
+        losses.append(tr.step(xs[b], ys[b], None if nxt is None else xs[nxt]))
+    torch.cuda.synchronize()
+    assert (tr._alt is not None) == (form == "alternating step graphs") and (tr._g_geo is not None) == (not form.startswith("forked"))
+    assert len(taps) == len(plan)
+    for i, ((b, _), read) in enumerate(zip(plan, taps)):
+        assert len(read) == len(want[b])
+        for j, (a, e) in enumerate(zip(read, want[b])):
+            assert (a is None) == (e is None), (form, i, j)
+            if a is not None:
+                assert a.shape == e.shape and torch.equal(a, e), "%s: step %d read a pyramid that is not batch %d's (tensor %d)" % (form, i, b, j)
+    assert all(torch.isfinite(l) for l in losses)
+
+
 def test_precomputed_geometry_is_identical(monkeypatch):
     torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
     model = fresh_model().eval()
