@@ -113,14 +113,30 @@ def active_switches():
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PN2_") and k != "PN2_BENCH_DRY_LAUNCH"}
 
 
-def kernel_source_hash():
-    """sha256 over the sources of the kernel the roofline prices: a PMC traffic figure is only quoted while it
-    was measured on exactly these sources."""
+def kernel_source_hash(names=("pn2_ball_grid.hip", "pn2_common.h")):
+    """sha256 over the translation unit of the kernel the roofline prices (pn2_ball_grid.hip and the one package header it
+    includes): a PMC traffic figure is only quoted while it was measured on exactly these sources."""
     h = hashlib.sha256()
-    for name in ("pn2_ball_grid.hip", "pn2_ball_binned.hip", "pn2_ball_bin.h", "pn2_common.h"):
+    for name in names:
         with open(os.path.join(REPO, "khairil_tum-facade_semantic_segmentation_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def measured_traffic():
+    """HBM bytes per launch of the operator-level kernel from the newest committed PMC record (profiles/rNN/ball_query_pmc.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH doubled per the gfx950 correction) whose
+    source hash equals the hash of the kernel's sources in this tree; None when no record matches."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "ball_query_pmc.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if pmc.get("source_sha256") == kernel_source_hash():
+            return pmc.get("traffic_bytes_per_launch"), os.path.relpath(path, REPO)
+    return None, None
 
 
 def run_control(args, dev):
@@ -493,14 +509,7 @@ def main():
     # HBM traffic of that launch cannot be read from inside this process: it is the rocprofv3 --pmc measurement
     # committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), quoted only while the
     # kernel sources are the ones it was measured on
-    traffic = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r03", "ball_query_pmc.json")) as fh:
-            pmc = json.load(fh)
-        if pmc.get("source_sha256") == kernel_source_hash():
-            traffic = pmc.get("traffic_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_record = measured_traffic()
 
     if rank == 0:
         total_points = world * PER_GPU_BATCH * BLOCK_POINTS * args.steps
@@ -527,7 +536,7 @@ def main():
                          "kernel": "operator level: pn2_ball_query_group, (xyz, new_xyz, feats) -> (idx, grouped) in one launch of "
                                    "ball_query_group_grid_kernel (SA1: N=4096,S=1024,K=32,D=9,B=16, %s)" % args.kind,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": algo, "kernel_ms": op_ms, "kernel_ms_single_launch": op_ms_single,
+                         "traffic": traffic, "traffic_record": traffic_record, "algorithmic_bytes": algo, "kernel_ms": op_ms, "kernel_ms_single_launch": op_ms_single,
                          "other_distribution": {"kind": other_kind, "kernel_ms": op_ms_o, "frac": frac(op_ms_o)},
                          "planned_pair": {
                              "what": "pn2_ball_plan (binning + row packing, one launch) + pn2_ball_query_group_planned "

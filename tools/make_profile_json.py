@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03/ from the outputs of tools/profile_ball.sh (gpurun_out/prof_r03/): copies the rocprofv3 summaries and
+"""profiles/<round>/ (PN2_ROUND, default r04) from the outputs of tools/profile_ball.sh (gpurun_out/prof_<round>/): copies the rocprofv3 summaries and
 writes ball_query_pmc.json -- for the OPERATOR-LEVEL kernel (ball_query_group_grid_kernel = pn2_ball_query_group, what
 bench.py's roofline.frac prices) and for the planned query (ball_query_binned_kernel): kernel durations, FETCH/WRITE
 traffic with the gfx950 correction, SQ counters, and the sha256 of the kernel sources they were measured on (bench.py
@@ -15,7 +15,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402
 
-src, dst = os.path.join(REPO, "gpurun_out", "prof_r03"), os.path.join(REPO, "profiles", "r03")
+ROUND = os.environ.get("PN2_ROUND", "r04")
+src, dst = os.path.join(REPO, "gpurun_out", "prof_" + ROUND), os.path.join(REPO, "profiles", ROUND)
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "*_kernel_stats.csv")) + glob.glob(os.path.join(src, "pmc_*_counter_collection.csv")):
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
@@ -60,6 +61,7 @@ j = {
                "{selfcontained,planned} ; rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/run_ball.py cube 5 <mode> ; same with "
                "--pmc WRITE_SIZE (separate passes) ; two SQ passes ; then tools/make_profile_json.py",
     "source_sha256": bench.kernel_source_hash(),
+    "planned_query_source_sha256": bench.kernel_source_hash(("pn2_ball_binned.hip", "pn2_ball_bin.h", "pn2_common.h")),
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reads exactly 1/2 of wide coalesced reads on gfx950 -> doubled; WRITE_SIZE exact",
     "algorithmic_bytes_per_launch": ALGO,
     # top level = the operator-level kernel (what bench.py's roofline.traffic quotes)

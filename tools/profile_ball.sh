@@ -1,9 +1,10 @@
 #!/bin/bash
 # rocprofv3 evidence for the roofline kernels (run on the GPU box from the repo root): kernel-trace stats of bench.py and of
 # the ball-query runner (operator-level entry and planned pair, both distributions), then FETCH_SIZE / WRITE_SIZE and SQ
-# counters in separate PMC passes.  Output: gpurun_out/prof_r03/ (tools/make_profile_json.py turns it into profiles/r03/).
+# counters in separate PMC passes.  Output: gpurun_out/prof_<round>/ (PN2_ROUND, default r04; tools/make_profile_json.py turns it
+# into profiles/<round>/).
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
-out="$root/gpurun_out/prof_r03"
+out="$root/gpurun_out/prof_${PN2_ROUND:-r04}"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, "rocprof options", program...
