@@ -296,7 +296,9 @@ def _capture(module, fn, inputs, stable, params, want_backward):
     inst.static_outputs = [o.detach() for o in outs]
     del outs, static_in, leaves
     for o in inst.static_outputs:
-        _STATIC[o.untyped_storage().data_ptr()] = True
+        ptr = o.untyped_storage().data_ptr()
+        _STATIC[ptr] = True
+        weakref.finalize(inst, _STATIC.pop, ptr, None)        # an address of a dead instance means nothing
     stats["captures"] += 1
     torch.cuda.current_stream(dev).synchronize()
     return inst

@@ -114,3 +114,77 @@ def test_scene_metrics_follow_the_loop_formulas():
     iou = correct / (union + 1e-6)
     assert abs(m["mIoU"] - iou.mean()) < 1e-12 and abs(m["scene_mIoU"] - iou[seen != 0].mean()) < 1e-12
     assert abs(m["accuracy"] - correct.sum() / (seen.sum() + 1e-6)) < 1e-12
+
+
+def test_runner_slots_split_and_initialisation():
+    """tools/run_facade.py's host pieces against the reference's formulas: room_idxs by point share
+    (sem_seg_training.py:184-193), the 70 / 30 split of the SLOTS (:434-441: both halves keep all rooms), weights_init (:554-561)."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_facade
+    pts = [5_000_000, 1_200_000, 300_000]
+    slots = run_facade.sample_slots(pts, 4096)
+    prob = np.array(pts) / sum(pts)
+    num_iter = int(sum(pts) / 4096)
+    want = sum(([r] * int(round(prob[r] * num_iter)) for r in range(3)), [])
+    assert slots.tolist() == want
+    tr, ev = run_facade.split_slots(slots, 3, 0.7, seed=3)
+    assert tr.sum() == int(0.7 * len(slots)) and (tr + ev).tolist() == np.bincount(slots, minlength=3).tolist()
+    assert (tr > 0).all() and (ev > 0).all()                          # every room is in both halves
+    assert abs(tr[0] / tr.sum() - prob[0]) < 0.03
+    tr2, _ = run_facade.split_slots(slots, 3, 0.7, seed=3)
+    assert tr2.tolist() == tr.tolist()                                # the split is a function of the seed
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 1), torch.nn.Conv1d(8, 8, 1), torch.nn.Linear(3, 3))
+    before = net[1].weight.detach().clone()
+    run_facade.init_weights(net)
+    assert float(net[0].bias.abs().max()) == 0.0 and float(net[2].bias.abs().max()) == 0.0
+    assert torch.equal(net[1].weight, before)                         # Conv1d: untouched, as in the reference
+    assert abs(float(net[0].weight.std()) - (2.0 / (4 + 8)) ** 0.5) < 0.15
+
+
+def test_gave_up_blocks_are_counted_over_every_draw_of_an_epoch():
+    """a block the sampler gave up on in ANY batch of an epoch must surface, not only one of the last batch."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd import train
+
+    class Sampler:
+        table = None
+    s = Sampler()
+    assert train.gave_up_blocks(s) == 0
+    for i in range(5):
+        info = torch.zeros((4, 4), dtype=torch.int32)
+        if i == 1:
+            info[2, 3] = 1                                            # one block of the SECOND batch
+        train._log_draw(s, info)
+    assert train.gave_up_blocks(s, clear=False) == 1
+    assert train.gave_up_blocks(s) == 1 and train.gave_up_blocks(s) == 0
+
+
+def test_module_graph_signatures_on_cpu():
+    """graphed.py's bookkeeping that needs no GPU: a CPU tensor never goes through a graph, the state key follows a replaced
+    parameter, a BatchNorm's mode and frozen parameters, and the storage use-count tells whether somebody still holds a view."""
+    import torch
+    from khairil_tum_facade_semantic_segmentation_amd import graphed
+    assert not graphed.usable(torch.zeros(2, 3, 8))
+    m = torch.nn.Sequential(torch.nn.Conv1d(3, 4, 1), torch.nn.BatchNorm1d(4))
+    p1, k1 = graphed._state(m)
+    assert len(p1) == 4
+    m[1].eval()
+    assert graphed._state(m)[1] != k1
+    m[1].train()
+    assert graphed._state(m)[1] == k1
+    m[0].weight.requires_grad_(False)
+    assert graphed._state(m)[1] != k1
+    m[0].weight = torch.nn.Parameter(torch.zeros(4, 3, 1))
+    p2, k2 = graphed._state(m)
+    assert p2[0] is m[0].weight and k2 != k1
+    t = torch.zeros(8)
+    base = graphed._use_count(t)
+    assert base == graphed._base_use()
+    v = t.view(2, 4)
+    assert graphed._use_count(t) == base + 1
+    del v
+    assert graphed._use_count(t) == base
