@@ -98,111 +98,6 @@ def sample_and_group_all(xyz, points):
     return new_xyz, grouped
 
 
-# ---------------------------------------------------------------------------------------- geometry ahead (drop-in mode)
-# A caller that wires the modules like the reference's pointnet2_sem_seg.py (sa1 -> sa2 -> sa3 -> sa4, then fp4 .. fp1 on
-# the same coordinate tensors) asks for eight pieces of geometry one after the other, each of which depends on the input
-# coordinates only.  The modules LEARN that wiring during the first forward pass (which tensor each call received: the
-# previous module's output, by storage identity) and from then on the first module of the chain computes the whole
-# pyramid -- FPS / ball query of every level, the 3-NN tables of every feature-propagation call -- on a side stream
-# the moment the input arrives; the later modules pick their piece up (an event wait) instead of computing it on the
-# critical stream.  No caller change.  OFF by default (PN2_DROPIN_AHEAD=1 enables it): measured on MI355X the drop-in step
-# is bound by the HOST's launch rate (about 250 eager launches: forward 2.05 ms of which 1.89 ms are enqueueing,
-# tools/dropin_probe.py), so moving geometry to another stream changes nothing the step waits for -- 4.7-5.4 ms either
-# way, inside the box-to-box spread.  It pays where the caller captures the step into a hipGraph itself.
-_AHEAD_ON = os.environ.get("PN2_DROPIN_AHEAD", "0") == "1"
-
-
-def _cf_key(t):
-    """Identity of a channel-first coordinate tensor as a caller passes it on: storage address, shape, strides."""
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
-
-
-class _GeometryAhead:
-    def __init__(self):
-        self.chains = {}          # id(head module) -> {"sa": [modules], "fp": [(module, lvl1, lvl2)]}
-        self.trace = None         # the pass being recorded: {"sa": [...], "keys": [key of level 0, 1, ...], "fp": [...]}
-        self.cache = {}           # key -> (event, payload) for the pass in flight
-        self.side = {}
-        self.hits = 0             # pieces of geometry served from the side stream (tests)
-
-    def stream(self, dev):
-        k = (dev.type, dev.index)
-        if k not in self.side:
-            self.side[k] = torch.cuda.Stream(device=dev)
-        return self.side[k]
-
-    # ---- learning
-    def saw_sa(self, module, key_in, key_out):
-        tr = self.trace
-        if tr is not None and tr["keys"][-1] == key_in:
-            tr["sa"].append(module)
-            tr["keys"].append(key_out)
-            return
-        self._finish()
-        self.trace = {"sa": [module], "keys": [key_in, key_out], "fp": []}
-
-    def saw_fp(self, module, key1, key2):
-        tr = self.trace
-        if tr is None:
-            return
-        if key1 in tr["keys"] and key2 in tr["keys"]:
-            tr["fp"].append((module, tr["keys"].index(key1), tr["keys"].index(key2)))
-        else:
-            self.trace = None     # coordinates this chain did not produce: not the wiring we know how to run ahead
-
-    def new_input(self, key_in):
-        """A set-abstraction call on coordinates that do not continue the pass being recorded: that pass is complete."""
-        if self.trace is not None and self.trace["keys"][-1] != key_in:
-            self._finish()
-
-    def _finish(self):
-        tr, self.trace = self.trace, None
-        if tr is not None and len(tr["sa"]) >= 2:
-            self.chains[id(tr["sa"][0])] = {"sa": list(tr["sa"]), "fp": list(tr["fp"])}
-
-    # ---- running ahead
-    def run(self, head, xyz_cf, xyz_cl):
-        """head = first module of a learned chain, called with coordinates xyz_cf ([B,3,N] as passed) = xyz_cl [B,N,3]."""
-        chain = self.chains[id(head)]
-        self.cache.clear()
-        dev = xyz_cl.device
-        main = torch.cuda.current_stream(dev)
-        side = self.stream(dev)
-        side.wait_stream(main)
-        xyz_cl.record_stream(side)
-        with torch.no_grad(), torch.cuda.stream(side):
-            levels, keys = [xyz_cl], [_cf_key(xyz_cf)]
-            for m in chain["sa"]:
-                new_xyz, idx = m.geometry(levels[-1])
-                ev = torch.cuda.Event()
-                ev.record(side)
-                for t in (new_xyz, idx):
-                    t.record_stream(main)
-                self.cache[("sa", id(m), keys[-1])] = (ev, (new_xyz, idx))
-                levels.append(new_xyz)
-                keys.append((new_xyz.data_ptr(), (new_xyz.shape[0], 3, new_xyz.shape[1]), (new_xyz.shape[1] * 3, 1, 3)))
-            for m, l1, l2 in chain["fp"]:
-                if levels[l2].shape[1] == 1:
-                    continue
-                idx3, w3 = ops.three_nn(levels[l1], levels[l2])
-                ev = torch.cuda.Event()
-                ev.record(side)
-                for t in (idx3, w3):
-                    t.record_stream(main)
-                self.cache[("fp", id(m), keys[l1], keys[l2])] = (ev, (levels[l1], idx3, w3))
-
-    def take(self, key):
-        hit = self.cache.pop(key, None)
-        if hit is None:
-            return None
-        torch.cuda.current_stream().wait_event(hit[0])
-        self.hits += 1
-        return hit[1]
-
-
-_AHEAD = _GeometryAhead()
-
-
 # PN2_TORCH_MLP=1 routes the conv/BN/ReLU stacks through torch ops (rocBLAS + ATen BatchNorm)
 # instead of the MFMA kernels of csrc/pn2_mlp.hip: an A/B switch for benchmarks and tests.
 _TORCH_MLP = os.environ.get("PN2_TORCH_MLP", "0") == "1"
@@ -314,8 +209,7 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
 
     def forward(self, xyz, points):
         """xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
-        ahead = _AHEAD_ON and xyz.is_cuda and not self.group_all
-        if not ahead and not self.group_all and not _TORCH_MLP and graphed.usable(xyz, points):
+        if not self.group_all and not _TORCH_MLP and graphed.usable(xyz, points):
             # repeated calls of one signature replay a captured forward / backward (graphed.py).  The FPS start indices are
             # an input of the graph, drawn here exactly as the eager path draws them (reference :75)
             start = _next_start(xyz.device)
@@ -323,22 +217,8 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
                 start = torch.randint(0, xyz.shape[2], (xyz.shape[0],), dtype=torch.long, device=xyz.device)
             new_xyz, feats = graphed.call(self, self._forward_rows, (xyz, points, start), lambda: _before_replay(self))
             return new_xyz.permute(0, 2, 1), feats.permute(0, 2, 1)
-        xyz_cl = xyz.permute(0, 2, 1)
-        points_cl = None if points is None else points.permute(0, 2, 1)
-        geometry = None
-        if ahead:
-            xyz_cl = xyz_cl.to(torch.float32).contiguous()
-            key = _cf_key(xyz)
-            _AHEAD.new_input(key)
-            geometry = _AHEAD.take(("sa", id(self), key))
-            if geometry is None and id(self) in _AHEAD.chains:
-                _AHEAD.run(self, xyz, xyz_cl)             # the whole learned pyramid, on the side stream, from here
-                geometry = _AHEAD.take(("sa", id(self), key))
-        new_xyz, feats = self.forward_cl(xyz_cl, points_cl, geometry=geometry)
-        out_xyz = new_xyz.permute(0, 2, 1)
-        if ahead and geometry is None:
-            _AHEAD.saw_sa(self, key, _cf_key(out_xyz))
-        return out_xyz, feats.permute(0, 2, 1)
+        new_xyz, feats = self.forward_cl(xyz.permute(0, 2, 1), None if points is None else points.permute(0, 2, 1))
+        return new_xyz.permute(0, 2, 1), feats.permute(0, 2, 1)
 
 
 class PointNetSetAbstractionMsg(nn.Module):             # reference :205-262
@@ -412,17 +292,8 @@ class PointNetFeaturePropagation(nn.Module):            # reference :265-315
 
     def forward(self, xyz1, xyz2, points1, points2):
         """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N]|None, points2 [B,D2,S] -> [B,D',N]."""
-        if not _AHEAD_ON and not _TORCH_MLP and graphed.usable(xyz1, xyz2, points1, points2):
+        if not _TORCH_MLP and graphed.usable(xyz1, xyz2, points1, points2):
             (y,) = graphed.call(self, self._forward_rows, (xyz1, xyz2, points1, points2), lambda: _before_replay(self))
-            return y.permute(0, 2, 1)
-        nn, x1 = None, xyz1.permute(0, 2, 1)
-        if _AHEAD_ON and xyz1.is_cuda:
-            k1, k2 = _cf_key(xyz1), _cf_key(xyz2)
-            hit = _AHEAD.take(("fp", id(self), k1, k2))
-            if hit is not None:
-                x1, nn = hit[0], (hit[1], hit[2])         # the channel-last coordinates and their 3-NN table, computed ahead
-            else:
-                _AHEAD.saw_fp(self, k1, k2)
-        y = self.forward_cl(x1, xyz2.permute(0, 2, 1),
-                            None if points1 is None else points1.permute(0, 2, 1), points2.permute(0, 2, 1), nn=nn)
+        else:
+            (y,) = self._forward_rows(xyz1, xyz2, points1, points2)
         return y.permute(0, 2, 1)

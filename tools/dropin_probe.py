@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the drop-in step's time goes (GPU box): forward / backward / optimizer wall time of the reference-wired model on
-the HIP pointnet2_utils, host-side enqueue time against GPU time, with the geometry-ahead chain on and off.
+the HIP pointnet2_utils, host-side enqueue time against GPU time, with the modules' own graphs on and off.
     python tools/dropin_probe.py"""
 import os
 import sys
@@ -29,12 +29,8 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     cw = torch.ones(18, device=dev)
     from khairil_tum_facade_semantic_segmentation_amd import graphed
-    for ahead, graphs in ((False, True), (False, False), (True, False), (False, True)):
-        U._AHEAD_ON = ahead
+    for graphs in (True, False, True, False):
         graphed.ENABLED = graphs
-        U._AHEAD.chains.clear()
-        U._AHEAD.trace = None
-        U._AHEAD.cache.clear()
         for _ in range(6):
             opt.zero_grad()
             loss_fn(model(x)[0].contiguous().view(-1, 18), y, cw).backward()
@@ -59,8 +55,8 @@ def main():
             torch.cuda.synchronize()
             t5 = time.perf_counter()
             hf += t1 - t0; tf += t2 - t0; hb += t3 - t2; tb += t4 - t2; to += t5 - t4
-        print("graphs=%-5s ahead=%-5s forward %.2f ms (host enqueue %.2f) | backward %.2f ms (host %.2f) | optimizer %.2f ms | sum %.2f ms"
-              % (graphs, ahead, tf / n * 1e3, hf / n * 1e3, tb / n * 1e3, hb / n * 1e3, to / n * 1e3, (tf + tb + to) / n * 1e3), flush=True)
+        print("module graphs=%-5s forward %.2f ms (host enqueue %.2f) | backward %.2f ms (host %.2f) | optimizer %.2f ms | sum %.2f ms"
+              % (graphs, tf / n * 1e3, hf / n * 1e3, tb / n * 1e3, hb / n * 1e3, to / n * 1e3, (tf + tb + to) / n * 1e3), flush=True)
 
 
 def profile():
@@ -74,7 +70,6 @@ def profile():
     model = model.to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     cw = torch.ones(18, device=dev)
-    U._AHEAD_ON = False
 
     def step():
         opt.zero_grad()
