@@ -6,6 +6,6 @@ keep=$(mktemp); cp "$pkg/libpn2hip.so" "$keep"; trap 'cp "$keep" "$pkg/libpn2hip
 for i in $(seq 1 "${1:-3}"); do
   for w in prev new; do
     cp "tools/ab_libs/libpn2hip_$w.so" "$pkg/libpn2hip.so"
-    python3 tools/ballbench.py 50 2>/dev/null | grep -E "plan\+query|grid " | sed "s/^/$w /"
+    python3 tools/ballbench.py 50 2>/dev/null | grep -E "plan\+query|grid3? +fused" | sed "s/^/$w /"
   done
 done
