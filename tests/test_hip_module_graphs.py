@@ -234,3 +234,66 @@ def test_momentum_schedule_reaches_a_replayed_module(orc, synth, monkeypatch):
     for a, b in zip(got, eager):
         _same(torch, a, b)
     assert not torch.equal(eager[5][3]["sa1.mlp_bns.0.running_mean"], eager[3][3]["sa1.mlp_bns.0.running_mean"])
+
+
+def test_unusual_callers_shared_module_two_forwards_retain_graph(orc, synth, monkeypatch):
+    """Callers the loop of the reference is not: ONE module applied to two inputs in a forward (its two calls must not share
+    buffers: the second runs on another instance while the first call's backward is pending, and the parameter gradients of
+    both arrive), two forwards before either backward, and backward(retain_graph=True) twice.  Every case against the eager
+    modules."""
+    torch, graphed, U, model, x, y, starts, K = _setup(synth, orc, seed=307)
+    sa = model.sa1.train()
+    xa = x
+    xb = torch.flip(x, dims=(2,)).contiguous()
+    s0 = starts[0]
+
+    def siamese():
+        sa.zero_grad(set_to_none=True)
+        with U.fps_starts([s0, s0]):
+            _, fa = sa(xa[:, :3, :], xa)
+            _, fb = sa(xb[:, :3, :], xb)
+        (fa.square().mean() + 2.0 * fb.mean()).backward()
+        return fa.detach().clone(), fb.detach().clone(), {k: p.grad.clone() for k, p in sa.named_parameters()}
+
+    def two_forwards():
+        sa.zero_grad(set_to_none=True)
+        with U.fps_starts([s0, s0]):
+            _, fa = sa(xa[:, :3, :], xa)
+            _, fb = sa(xb[:, :3, :], xb)
+        la, lb = fa.square().mean(), fb.abs().mean()
+        lb.backward()
+        gb = {k: p.grad.clone() for k, p in sa.named_parameters()}
+        la.backward()
+        return fa.detach().clone(), fb.detach().clone(), gb, {k: p.grad.clone() for k, p in sa.named_parameters()}
+
+    def retained():
+        sa.zero_grad(set_to_none=True)
+        with U.fps_starts([s0]):
+            _, fa = sa(xa[:, :3, :], xa)
+        loss = fa.square().mean()
+        loss.backward(retain_graph=True)
+        once = {k: p.grad.clone() for k, p in sa.named_parameters()}
+        loss.backward()
+        return once, {k: p.grad.clone() for k, p in sa.named_parameters()}
+
+    def grads_close(a, b):
+        for k in b:
+            if k.endswith(".bias") and "mlp_convs" in k:
+                continue
+            assert _close(a[k], b[k], 2e-5), k
+    state = {k: v.clone() for k, v in sa.state_dict().items()}
+    for case in (siamese, two_forwards, retained):
+        monkeypatch.setattr(graphed, "ENABLED", False)
+        sa.load_state_dict(state)
+        want = [case() for _ in range(5)]
+        monkeypatch.setattr(graphed, "ENABLED", True)
+        sa.load_state_dict(state)
+        before = graphed.stats["replays"]
+        for i in range(5):
+            got = case()
+            for a, b in zip(got, want[i]):
+                if isinstance(b, dict):
+                    grads_close(a, b)
+                else:
+                    assert torch.equal(a, b)
+        assert graphed.stats["replays"] > before, case.__name__
