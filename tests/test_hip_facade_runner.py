@@ -130,6 +130,13 @@ def test_runner_trains_evaluates_checkpoints_and_labels_a_scene(tmp_path):
     assert os.path.exists(os.path.join(out, "model.pth"))                               # epoch 0: `epoch % 5 == 0`
     with open(os.path.join(out, "results.json")) as fh:
         assert json.load(fh)["mIoU"] == res["mIoU"]
+    # sem_seg_testing.py's job alone: the checkpoint file just written, no training data needed
+    os.remove(os.path.join(root, "room_a.las"))
+    os.remove(os.path.join(root, "room_b.las"))
+    _, targs = runner_args(root, str(tmp_path / "out_test_only"), ["--test-only", "--checkpoint", os.path.join(out, "best_model.pth")])
+    again = run_facade.run(targs, log=lambda *a: None)
+    assert again["history"] == [] and again["scenes"][0]["labels_written"] == P
+    assert abs(again["accuracy"] - res["accuracy"]) < 0.03 and abs(again["mIoU"] - res["mIoU"]) < 0.03   # other FPS starts, same model
 
 
 def _rank_worker(rank, world, port, root, out):

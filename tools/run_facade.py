@@ -11,6 +11,7 @@ they are but need laspy / open3d / h5py, absent here), restated on the package's
     DeviceSceneTiler -> infer_scene (votes on the device) -> IoU, labels sem_seg_testing.py:182-254, localfunctions.py:349-479
 
     python tools/run_facade.py --data DIR --test-area NAME.las --epochs 25 [--class8] [--no-color] [--gpus N] [--oracle]
+    python tools/run_facade.py --data DIR --test-area NAME.las --test-only [--checkpoint best_model.pth] ...   (sem_seg_testing.py alone)
 
 --gpus N starts N ranks (one per GPU) under torch.distributed.run: every rank draws its own blocks (the rank is in the
 sampler seed), ONE all-reduce of the packed gradients per step, and the test scene's sub-batches are sharded over the ranks
@@ -150,78 +151,86 @@ def run(args, log=print):
     files = sorted(glob.glob(os.path.join(args.data, "*.las")))
     train_files = [f for f in files if not f.endswith(args.test_area)]                     # sem_seg_training.py:359
     test_files = [f for f in files if f.endswith(args.test_area)]
-    if not train_files or not test_files:
+    if not test_files or not (train_files or args.test_only):
         raise SystemExit("need at least one training .las and the test area %r under %s (found %d files)"
                          % (args.test_area, args.data, len(files)))
-    t0 = time.time()
-    rooms = [load_room(f, args.class8, color) for f in train_files]
-    say("read %d training rooms, %d points, in %.1f s" % (len(rooms), sum(r["xyz"].shape[0] for r in rooms), time.time() - t0))
-    E = len(rooms[0]["feature_name"])
-    weights = train.label_weights([r["labels"] for r in rooms], C, device=dev)              # :264-278, :533-536
-    slots = sample_slots([r["xyz"].shape[0] for r in rooms], args.npoint)
-    tr_slots, ev_slots = split_slots(slots, len(rooms), 0.7, args.seed)
-    steps = int(tr_slots.sum()) // args.batch_size if args.steps_per_epoch is None else args.steps_per_epoch   # drop_last=True, :524-528
-    eval_steps = int(ev_slots.sum()) // args.batch_size if args.eval_steps is None else args.eval_steps
-    if steps < 1:
-        raise SystemExit("the training rooms hold fewer than one batch of %d x %d-point slots" % (args.batch_size, args.npoint))
-    say("%d slots (%d train, %d eval): %d training steps per epoch per rank, %d evaluation batches; class weights %s"
-        % (len(slots), int(tr_slots.sum()), int(ev_slots.sum()), steps, eval_steps, np.round(weights.cpu().numpy(), 3).tolist()))
-    samplers = [scene.DeviceBlockSampler(r["xyz"], r["labels"], r["extra"], r["feature_name"], args.npoint, device=dev) for r in rooms]
-    tr_sampler, ev_sampler = scene.MultiRoomSampler(samplers), scene.MultiRoomSampler(samplers)
-    tr_sampler.sizes = [max(float(v), 1e-9) for v in tr_slots]        # a block's room is drawn by the split's share of slots
-    ev_sampler.sizes = [max(float(v), 1e-9) for v in ev_slots]
-
-    torch.manual_seed(args.seed)
-    model = M.get_model(C, E)
-    init_weights(model)
-    model = model.to(dev)
-    trainer = train.SemSegTrainer(model, lr=args.learning_rate, weight_decay=args.decay_rate, class_weight=weights, graphs=True,
-                                  prefetch_geometry=True, augment=True, metrics=True)
-    start_epoch = 0
     os.makedirs(args.out, exist_ok=True)
     best_path = os.path.join(args.out, "best_model.pth")
-    if args.resume and os.path.exists(best_path):
-        start_epoch = int(train.load_checkpoint(best_path, model, trainer)["epoch"])      # sem_seg_training.py:566-570
-        say("resumed from %s at epoch %d" % (best_path, start_epoch))
-    if use_dist:
-        x0, y0 = train.draw_batch(tr_sampler, args.batch_size, args.seed, 0, 0, rank)
-        trainer.prepare(x0, y0)                                        # capture BEFORE the first collective
-    trainer.broadcast_parameters()
-    best = train.BestModel(best_path if rank == 0 else None)
-    engine = scene.BlockInferencer(model, args.batch_size, 6 + E, args.npoint)
     history = []
-    for epoch in range(start_epoch, args.epochs):
+    if args.test_only:
+        # sem_seg_testing.py: no training; the checkpoint the training driver left (its 'model_state_dict', :496-497)
+        E = 3 if color else 0
+        model = M.get_model(C, E).to(dev)
+        ck = train.load_checkpoint(args.checkpoint or best_path, model)
+        say("loaded %s (epoch %s, class_avg_iou %s)" % (args.checkpoint or best_path, ck.get("epoch"), ck.get("class_avg_iou")))
+        engine = scene.BlockInferencer(model, args.batch_size, 6 + E, args.npoint)
+    else:
         t0 = time.time()
-        model.train()
-        tr = train.train_epoch(trainer, tr_sampler, epoch, steps, args.batch_size, seed=args.seed, learning_rate=args.learning_rate,
-                               lr_decay=args.lr_decay, step_size=args.step_size)
-        torch.cuda.synchronize(dev)
-        t_train = time.time() - t0
-        # an empty ball-query neighbourhood is an IndexError in the reference (pointnet2_utils.py:59); here it is counted on
-        # the device and raised once per epoch (raw coordinates whose squares swamp r^2 in fp32 are the usual cause)
-        ops.check_errors(dev, "training epoch %d" % epoch)
-        if epoch % 5 == 0 and rank == 0:                               # localfunctions.py:229-239
-            train.save_checkpoint(os.path.join(args.out, "model.pth"), epoch, model, trainer)
-        ev = None
-        if eval_steps > 0:
-            # the evaluation half draws random blocks too (the reference's eval dataset is the same class); every rank
-            # draws the same ones (no rank in the seed) from its own replica
-            batches = [train.draw_batch(ev_sampler, args.batch_size, args.seed + 7919, epoch, i, 0) for i in range(eval_steps)]
-            if train.gave_up_blocks(ev_sampler):
-                raise RuntimeError("the block sampler gave up on evaluation blocks: a room without a 1 m column of > 1024 points")
-            ev = train.eval_epoch(model, batches, class_weight=weights, engine=engine)
-            del batches
-            best.update(epoch, ev["mIoU"], model, trainer)
-        rec = {"epoch": epoch, "train_loss": tr["loss"], "train_accuracy": tr.get("accuracy"), "lr": tr["lr"],
-               "bn_momentum": tr["bn_momentum"], "train_seconds": t_train,
-               "train_points_per_s": world * steps * args.batch_size * args.npoint / t_train}
-        if ev is not None:
-            rec.update({"eval_loss": ev["loss"], "eval_mIoU": ev["mIoU"], "eval_accuracy": ev["accuracy"], "best_mIoU": best.best_iou})
-        history.append(rec)
-        say(json.dumps(rec))
-    if best.state is not None:
-        model.load_state_dict(best.state)                              # sem_seg_testing.py:496-497 loads best_model.pth
-    trainer.broadcast_parameters()                                     # BatchNorm statistics are rank-local: rank 0's model votes
+        rooms = [load_room(f, args.class8, color) for f in train_files]
+        say("read %d training rooms, %d points, in %.1f s" % (len(rooms), sum(r["xyz"].shape[0] for r in rooms), time.time() - t0))
+        E = len(rooms[0]["feature_name"])
+        weights = train.label_weights([r["labels"] for r in rooms], C, device=dev)              # :264-278, :533-536
+        slots = sample_slots([r["xyz"].shape[0] for r in rooms], args.npoint)
+        tr_slots, ev_slots = split_slots(slots, len(rooms), 0.7, args.seed)
+        steps = int(tr_slots.sum()) // args.batch_size if args.steps_per_epoch is None else args.steps_per_epoch   # drop_last=True, :524-528
+        eval_steps = int(ev_slots.sum()) // args.batch_size if args.eval_steps is None else args.eval_steps
+        if steps < 1:
+            raise SystemExit("the training rooms hold fewer than one batch of %d x %d-point slots" % (args.batch_size, args.npoint))
+        say("%d slots (%d train, %d eval): %d training steps per epoch per rank, %d evaluation batches; class weights %s"
+            % (len(slots), int(tr_slots.sum()), int(ev_slots.sum()), steps, eval_steps, np.round(weights.cpu().numpy(), 3).tolist()))
+        samplers = [scene.DeviceBlockSampler(r["xyz"], r["labels"], r["extra"], r["feature_name"], args.npoint, device=dev) for r in rooms]
+        tr_sampler, ev_sampler = scene.MultiRoomSampler(samplers), scene.MultiRoomSampler(samplers)
+        tr_sampler.sizes = [max(float(v), 1e-9) for v in tr_slots]        # a block's room is drawn by the split's share of slots
+        ev_sampler.sizes = [max(float(v), 1e-9) for v in ev_slots]
+
+        torch.manual_seed(args.seed)
+        model = M.get_model(C, E)
+        init_weights(model)
+        model = model.to(dev)
+        trainer = train.SemSegTrainer(model, lr=args.learning_rate, weight_decay=args.decay_rate, class_weight=weights, graphs=True,
+                                      prefetch_geometry=True, augment=True, metrics=True)
+        start_epoch = 0
+        if args.resume and os.path.exists(best_path):
+            start_epoch = int(train.load_checkpoint(best_path, model, trainer)["epoch"])      # sem_seg_training.py:566-570
+            say("resumed from %s at epoch %d" % (best_path, start_epoch))
+        if use_dist:
+            x0, y0 = train.draw_batch(tr_sampler, args.batch_size, args.seed, 0, 0, rank)
+            trainer.prepare(x0, y0)                                        # capture BEFORE the first collective
+        trainer.broadcast_parameters()
+        best = train.BestModel(best_path if rank == 0 else None)
+        engine = scene.BlockInferencer(model, args.batch_size, 6 + E, args.npoint)
+        for epoch in range(start_epoch, args.epochs):
+            t0 = time.time()
+            model.train()
+            tr = train.train_epoch(trainer, tr_sampler, epoch, steps, args.batch_size, seed=args.seed, learning_rate=args.learning_rate,
+                                   lr_decay=args.lr_decay, step_size=args.step_size)
+            torch.cuda.synchronize(dev)
+            t_train = time.time() - t0
+            # an empty ball-query neighbourhood is an IndexError in the reference (pointnet2_utils.py:59); here it is counted on
+            # the device and raised once per epoch (raw coordinates whose squares swamp r^2 in fp32 are the usual cause)
+            ops.check_errors(dev, "training epoch %d" % epoch)
+            if epoch % 5 == 0 and rank == 0:                               # localfunctions.py:229-239
+                train.save_checkpoint(os.path.join(args.out, "model.pth"), epoch, model, trainer)
+            ev = None
+            if eval_steps > 0:
+                # the evaluation half draws random blocks too (the reference's eval dataset is the same class); every rank
+                # draws the same ones (no rank in the seed) from its own replica
+                batches = [train.draw_batch(ev_sampler, args.batch_size, args.seed + 7919, epoch, i, 0) for i in range(eval_steps)]
+                if train.gave_up_blocks(ev_sampler):
+                    raise RuntimeError("the block sampler gave up on evaluation blocks: a room without a 1 m column of > 1024 points")
+                ev = train.eval_epoch(model, batches, class_weight=weights, engine=engine)
+                del batches
+                best.update(epoch, ev["mIoU"], model, trainer)
+            rec = {"epoch": epoch, "train_loss": tr["loss"], "train_accuracy": tr.get("accuracy"), "lr": tr["lr"],
+                   "bn_momentum": tr["bn_momentum"], "train_seconds": t_train,
+                   "train_points_per_s": world * steps * args.batch_size * args.npoint / t_train}
+            if ev is not None:
+                rec.update({"eval_loss": ev["loss"], "eval_mIoU": ev["mIoU"], "eval_accuracy": ev["accuracy"], "best_mIoU": best.best_iou})
+            history.append(rec)
+            say(json.dumps(rec))
+        if best.state is not None:
+            model.load_state_dict(best.state)                              # sem_seg_testing.py:496-497 loads best_model.pth
+        trainer.broadcast_parameters()                                     # BatchNorm statistics are rank-local: rank 0's model votes
 
     # ---- whole-scene test (sem_seg_testing.py + modelTesting)
     results = {"history": history, "classes": classes, "world_size": world, "scenes": []}
@@ -322,6 +331,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--test-only", action="store_true",
+                    help="sem_seg_testing.py's job alone: load --checkpoint (default <out>/best_model.pth) and label the test area")
+    ap.add_argument("--checkpoint", default=None)
     ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle network on the test scene's tiles (slow)")
     ap.add_argument("--oracle-max-blocks", type=int, default=None)
     ap.add_argument("--keep-group", dest="destroy_group", action="store_false")
