@@ -92,6 +92,35 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ y, int ldy,
     }
 }
 
+// The class weights [C][K] on their way into LDS (row pitch ld): every load of a thread is issued before its first store
+// -- a `load; store` loop waits for one memory round trip per pass at the head of the launch -- and the caller stages its
+// first tile of rows between load() and store(), so that both travel in one round trip.  Rows past C and columns past K
+// are stored as zeros when `pad`.
+struct HeadWeights {
+    static constexpr int PASSES = HD_CMAX * (HD_KMAX / 4) / HD_THREADS;      // 4
+    float4 v[PASSES];
+    // element e = (class j = e / k4n, four columns at 4 * (e % k4n)); columns from 4 * kvalid on do not exist in w
+    __device__ __forceinline__ void load(const float *__restrict__ w, int K, int C, int k4n, int kvalid, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int e = tid + i * HD_THREADS;
+            const int j = e / k4n, q = e - j * k4n;
+            v[i] = *reinterpret_cast<const float4 *>(&w[(size_t)min(j, C - 1) * K + 4 * (q < kvalid ? q : 0)]);
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ sW, int ld, int C, int k4n, int kvalid, int rows, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int e = tid + i * HD_THREADS;
+            const int j = e / k4n, q = e - j * k4n;
+            if (j < rows)
+                *reinterpret_cast<float4 *>(&sW[j * ld + 4 * q]) = (j < C && q < kvalid) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+};
+
 // ---- forward -----------------------------------------------------------------------------------------
 // tile -> LDS, thread (row = t & 63, jq = t >> 6) accumulates classes jq, jq+4, ... over k in the
 // order k = 0..K-1 (one fma chain per class), then one thread per row does the log-softmax.
@@ -108,12 +137,11 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_kernel(const float *__
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * HD_ROWS;
     const int k4n = K >> 2;
-    for (int e = tid; e < C * k4n; e += HD_THREADS) {
-        const int j = e / k4n, q = e - j * k4n;
-        *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
-    }
+    HeadWeights hw;
+    hw.load(w, K, C, k4n, k4n, tid);
     const unsigned long long seed0 = drop_seed_value(drop);      // read ONCE per workgroup (see drop_count_call)
     stage_rows(y, ldy, row0, M, k4n, sY, tid, drop, seed0);
+    hw.store(sW, HD_KMAX, C, k4n, k4n, C, tid);
     __syncthreads();
     const int r = tid & 63, jq = tid >> 6;
     float acc[CQ];
@@ -182,12 +210,11 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_mfma_kernel(const floa
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * HD_ROWS;
     constexpr int k4n = HD_KMAX / 4;
-    for (int e = tid; e < C * k4n; e += HD_THREADS) {
-        const int j = e / k4n, q = e - j * k4n;
-        *reinterpret_cast<float4 *>(&sW[j * HD_LDW + 4 * q]) = *reinterpret_cast<const float4 *>(&w[(size_t)j * HD_KMAX + 4 * q]);
-    }
+    HeadWeights hw;
+    hw.load(w, HD_KMAX, C, k4n, k4n, tid);
     const unsigned long long seed0 = drop_seed_value(drop);      // read ONCE per workgroup (see drop_count_call)
     stage_rows(y, ldy, row0, M, k4n, sY, tid, drop, seed0);
+    hw.store(sW, HD_LDW, C, k4n, k4n, C, tid);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int rb = wave & 1, kh = wave >> 1;
@@ -256,11 +283,10 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_kernel(
     const int tid = threadIdx.x;
     const int k4n = K >> 2;
     const int ntiles = (M + HD_ROWS - 1) / HD_ROWS;
-    for (int e = tid; e < HD_CMAX * (HD_KMAX / 4); e += HD_THREADS) {
-        const int j = e / (HD_KMAX / 4), q = e - j * (HD_KMAX / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < C && q < k4n) v = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
-        *reinterpret_cast<float4 *>(&sW[j * HD_KMAX + 4 * q]) = v;
+    {
+        HeadWeights hw;
+        hw.load(w, K, C, HD_KMAX / 4, k4n, tid);
+        hw.store(sW, HD_KMAX, C, HD_KMAX / 4, k4n, HD_CMAX, tid);
     }
     // dW ownership: k = tid & 127, classes 16*(tid >> 7) .. +15
     const int wk = tid & 127, wj0 = (tid >> 7) * 16;
@@ -367,11 +393,10 @@ __global__ __launch_bounds__(HD_THREADS) void head_logits_backward_mfma_kernel(
     constexpr int K = HD_KMAX, k4n = HD_KMAX / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int ntiles = (M + HD_ROWS - 1) / HD_ROWS;
-    for (int e = tid; e < HD_CMAX * k4n; e += HD_THREADS) {
-        const int j = e / k4n, q = e - j * k4n;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < C) v = *reinterpret_cast<const float4 *>(&w[(size_t)j * K + 4 * q]);
-        *reinterpret_cast<float4 *>(&sW[j * HD_LDW + 4 * q]) = v;
+    {
+        HeadWeights hw;
+        hw.load(w, K, C, k4n, k4n, tid);
+        hw.store(sW, HD_LDW, C, k4n, k4n, HD_CMAX, tid);
     }
     hd_f32x16 accW;                                           // dW[class][32 wave + (lane & 31)]
 #pragma unroll
@@ -672,7 +697,8 @@ PN2_EXPORT int pn2_head_logits_dropout_backward(const float *glogp, const float 
 
 PN2_EXPORT int pn2_nll_loss_partials(long long M)
 {
-    const long long b = (M + 1023) / 1024;
+    const long long b = (M + 255) / 256;                  // one row per thread up to 65 536 rows: target -> weight -> logp is three
+                                                          // dependent loads, a second row per thread is three more round trips
     return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 

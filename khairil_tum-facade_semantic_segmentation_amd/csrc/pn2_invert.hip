@@ -137,7 +137,10 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float *__restrict
     const int32_t *be = entries + (size_t)b * E;
     const float *bw = weight ? weight + (size_t)b * E : nullptr;
     const float *bs = src + (size_t)b * rows_src * lds + col0;
-    for (int c0 = 0; c0 < D; c0 += 4 * LPR) {
+    // blockIdx.y = block of 4 * LPR columns (wide rows: D up to 768 at the deep levels).  As a loop inside the workgroup the
+    // column blocks ran one after the other, each with its own entry -> weight / row round trips.
+    {
+        const int c0 = (int)blockIdx.y * 4 * LPR;
         const int c = c0 + sub * 4;
         const bool col_ok = c < D;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -278,7 +281,8 @@ PN2_EXPORT int pn2_gather_sum_add(const float *src, long long rows_src, int lds,
     const long long rpb = lpr ? 256 / (lpr * sl) : 4;
     const long long blocks = (rows + rpb - 1) / rpb;
     if (blocks > 0x7fffffffLL) return PN2_ERR_UNSUPPORTED;
-#define PN2_GS(L, S) hipLaunchKernelGGL((gather_sum_kernel<L, S>), dim3((unsigned)blocks), dim3(256), 0, stream, src, rows_src, lds, col0, \
+    const unsigned colblocks = lpr ? (unsigned)((D + 4 * lpr - 1) / (4 * lpr)) : 1u;
+#define PN2_GS(L, S) hipLaunchKernelGGL((gather_sum_kernel<L, S>), dim3((unsigned)blocks, colblocks), dim3(256), 0, stream, src, rows_src, lds, col0, \
                                         offsets, entries, weight, E, ediv, B, Nkeys, D, addend, out)
     if (lpr == 8) { if (sl == 4) PN2_GS(8, 4); else PN2_GS(8, 1); }
     else if (lpr == 16) { if (sl == 4) PN2_GS(16, 4); else PN2_GS(16, 1); }

@@ -2020,13 +2020,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
     float s = 0.f, q = 0.f;
     if (c < C) {
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-        for (long long r = (long long)blockIdx.x * 8 + ry; r < rows; r += (long long)gridDim.x * 8) {
-            const float gv = g[(size_t)r * ldg + c];
-            const long long zr = argk ? r * pool_k + argk[(size_t)r * C + c] : r;
-            const float zv = z[(size_t)zr * ldz + c];
-            const float gh = (sc * zv + sh) > 0.f ? gv : 0.f;
-            s += gh;
-            q += gh * ((zv - mu) * is);
+        // four rows per pass, every load of a stage issued before the first use: g / argk, then the gathered z -- two
+        // memory round trips per four rows instead of three per row (the launch is nothing but these round trips)
+        const long long stride = (long long)gridDim.x * 8;
+        for (long long r0 = (long long)blockIdx.x * 8 + ry; r0 < rows; r0 += 4 * stride) {
+            float gv[4], zv[4];
+            long long zr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = r0 + u * stride < rows ? r0 + u * stride : rows - 1;
+                gv[u] = g[(size_t)r * ldg + c];
+                zr[u] = argk ? r * pool_k + argk[(size_t)r * C + c] : r;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) zv[u] = z[(size_t)zr[u] * ldz + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + u * stride < rows) {
+                    const float gh = (sc * zv[u] + sh) > 0.f ? gv[u] : 0.f;
+                    s += gh;
+                    q += gh * ((zv[u] - mu) * is);
+                }
+            }
         }
     }
     sS[ry][cl] = s;
@@ -2593,8 +2608,10 @@ PN2_EXPORT int pn2_mlp_dw(const float *g, int ldg, const float *z, int ldz, cons
 
 PN2_EXPORT int pn2_bn_bwd_reduce_partials(long long rows)
 {
-    const long long b = (rows + 63) / 64;
-    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+    // 8 row slots per workgroup x 4 rows per pass: one pass per thread up to 16 384 rows; bn_bwd_finalize sums up to 512
+    // partials in one round trip
+    const long long b = (rows + 31) / 32;
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 PN2_EXPORT int pn2_bn_bwd_reduce(const float *g, int ldg, const float *z, int ldz, long long rows, int C,

@@ -34,6 +34,34 @@ struct BwdArgs {
     int M, N, K;
 };
 
+// The weight tile [NP][KP] on its way from global memory to LDS: every load of a thread is issued before the first
+// store (a `load; store` loop waits for one memory round trip per pass: 6-8 of them at the head of every launch), the
+// addresses are clamped and the values masked when stored, and the caller may issue its first tile's loads in between.
+template <int NP, int KP, int THREADS>
+struct WeightTile {
+    static constexpr int TOTAL = NP * (KP / 4), PASSES = (TOTAL + THREADS - 1) / THREADS;
+    float4 v[PASSES];
+    __device__ __forceinline__ void load(const float *w, int ldw, int N, int K, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int e = tid + i * THREADS;
+            const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
+            v[i] = *reinterpret_cast<const float4 *>(w + (size_t)min(n, N - 1) * ldw + (k4 < K ? k4 : 0));
+        }
+    }
+    __device__ __forceinline__ void store(float *sW, int N, int K, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int e = tid + i * THREADS;
+            const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
+            if (TOTAL % THREADS == 0 || e < TOTAL)
+                *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = (n < N && k4 < K) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+};
+
 template <int NBLK, int KBLK, bool POOLED>
 __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bwd_fused_kernel(BwdArgs p)
 {
@@ -55,12 +83,8 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
     const int ntiles = (p.M + FB_ROWS - 1) / FB_ROWS;
     const bool masked = p.ascale != nullptr;
 
-    for (int e = tid; e < NP * (KP / 4); e += FB_THREADS) {
-        const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.N && k4 < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k4);
-        *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = v;
-    }
+    WeightTile<NP, KP, FB_THREADS> wt;
+    wt.load(p.w, p.ldw, p.N, p.K, tid);
 
     // staging ownership: dz columns dc4..dc4+3, rows dr + DROWS*i; input columns xc4.., rows xr + XROWS*i
     const int dc4 = (tid % (NP / 4)) * 4, dr = tid / (NP / 4);
@@ -127,6 +151,7 @@ __global__ __launch_bounds__(FB_THREADS, (NBLK * KBLK <= 4) ? 4 : 2) void mlp_bw
         }
     };
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    wt.store(sW, p.N, p.K, tid);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * FB_ROWS;
@@ -323,12 +348,8 @@ __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
     const int Kout = p.K + 1;
     float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout;
 
-    for (int e = tid; e < NP * (KP / 4); e += FB_THREADS) {
-        const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.N && k4 < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k4);
-        *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = v;
-    }
+    WeightTile<NP, KP, FB_THREADS> wt;
+    wt.load(p.w, p.ldw, p.N, p.K, tid);
 
     // The two roles are two separate code paths (wave-uniform branch), each with its own registers; both
     // execute exactly the same sequence of barriers: A (weights in LDS), B (first tile staged), one per tile.
@@ -404,6 +425,7 @@ __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
             }
         };
         issue(t0);
+        wt.store(sW, p.N, p.K, tid);
         __syncthreads();                              // A
         commit(t0, 0);
         if (t0 + G < ntiles) issue(t0 + G);
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(FB_THREADS, 4) void mlp_bwd_split_kernel(BwdArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW[r] = 0.f;
         asm volatile("" ::"v"(xsc), "v"(xsh), "v"(xmu), "v"(xis));   // arrived before the loop (in-order vmcnt)
+        wt.store(sW, p.N, p.K, tid);
         __syncthreads();                              // A
         __syncthreads();                              // B
         int buf = 0;
@@ -582,12 +605,8 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
     const int Kout = Ktot + 1;
     float *slab = p.dw_partial + (size_t)blockIdx.x * p.N * Kout + k0;
 
-    for (int e = tid; e < NP * (KP / 4); e += THREADS) {
-        const int n = e / (KP / 4), k4 = (e - n * (KP / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.N && k4 < p.K) v = *reinterpret_cast<const float4 *>(p.w + (size_t)n * p.ldw + k4);
-        *reinterpret_cast<float4 *>(&sW[n * KP + k4]) = v;
-    }
+    WeightTile<NP, KP, THREADS> wt;
+    wt.load(p.w, p.ldw, p.N, p.K, tid);
 
     if (wave >= NMW) {
         // ================================ stagers =================================================
@@ -661,6 +680,7 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
             }
         };
         issue(t0);
+        wt.store(sW, p.N, p.K, tid);
         __syncthreads();                              // A
         commit(t0, 0);
         if (t0 + G < ntiles) issue(t0 + G);
@@ -714,6 +734,7 @@ __global__ __launch_bounds__(64 * (NMW + NSW), 2) void mlp_bwd_split2_kernel(Bwd
         for (int i = 0; i < DXPW; ++i) asm volatile("" ::"v"(xsc[i]), "v"(xsh[i]), "v"(xmu[i]), "v"(xis[i]));
 #pragma unroll
         for (int i = 0; i < DWPW; ++i) asm volatile("" ::"v"(wsc[i]), "v"(wsh[i]));
+        wt.store(sW, p.N, p.K, tid);
         __syncthreads();                              // A
         __syncthreads();                              // B
         int buf = 0;
