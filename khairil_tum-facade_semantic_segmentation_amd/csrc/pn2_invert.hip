@@ -32,9 +32,15 @@ __device__ __forceinline__ void invert_index_body(const int64_t *__restrict__ id
     const int64_t *bi = idx + (size_t)b * E;
     for (int i = tid; i <= Nkeys; i += INV_THREADS) cnt[i] = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += INV_THREADS) {
-        const int64_t k = bi[e];
-        if (k >= 0 && k < Nkeys) atomicAdd(&cnt[(int)k], 1);
+    // four keys per pass, loaded before the first is counted: the workgroup is alone on its CU and a pass is one memory
+    // round trip whatever it holds
+    for (long long e0 = tid; e0 < E; e0 += 4 * INV_THREADS) {
+        int64_t k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k4[u] = bi[min(e0 + u * INV_THREADS, E - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * INV_THREADS < E && k4[u] >= 0 && k4[u] < Nkeys) atomicAdd(&cnt[(int)k4[u]], 1);
     }
     __syncthreads();
     // exclusive scan over Nkeys counts: chunk per thread, wave scan, wave offsets
@@ -64,12 +70,12 @@ __device__ __forceinline__ void invert_index_body(const int64_t *__restrict__ id
     __syncthreads();
     // entries are appended batch by batch in ascending order (a barrier between batches), so a list is
     // ascending except among entries of one batch; the insertion sort below only repairs those
+    int64_t knext = bi[min((long long)tid, E - 1)];                // the next batch's key travels during this batch
     for (long long e0 = 0; e0 < E; e0 += INV_THREADS) {
         const long long e = e0 + tid;
-        if (e < E) {
-            const int64_t k = bi[e];
-            if (k >= 0 && k < Nkeys) list[atomicAdd(&fill[(int)k], 1)] = (int)e;
-        }
+        const int64_t k = knext;
+        knext = bi[min(e + INV_THREADS, E - 1)];
+        if (e < E && k >= 0 && k < Nkeys) list[atomicAdd(&fill[(int)k], 1)] = (int)e;
         __syncthreads();
     }
     // ascending order inside every list (insertion sort, one thread per key)

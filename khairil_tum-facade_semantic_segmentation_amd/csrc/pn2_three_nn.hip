@@ -57,10 +57,19 @@ __device__ __forceinline__ void three_nn_body(
     for (int s0 = 0; s0 < S; s0 += NN_TILE) {
         if (s0) __syncthreads();
         const int ns = min(NN_TILE, S - s0);
-        for (int j = tid; j < ns; j += NN_THREADS) {
-            const float x = b2[(size_t)(s0 + j) * 3 + 0], y = b2[(size_t)(s0 + j) * 3 + 1],
-                        z = b2[(size_t)(s0 + j) * 3 + 2];
-            src[j] = make_float4(x, y, z, pn2::norm3(x, y, z));
+        {   // every source of the tile is loaded before the first is stored (one memory round trip, not one per pass)
+            constexpr int PASSES = NN_TILE / NN_THREADS;
+            float sx[PASSES], sy[PASSES], sz[PASSES];
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                const size_t o = (size_t)(s0 + min(tid + u * NN_THREADS, ns - 1)) * 3;
+                sx[u] = b2[o]; sy[u] = b2[o + 1]; sz[u] = b2[o + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                const int j = tid + u * NN_THREADS;
+                if (j < ns) src[j] = make_float4(sx[u], sy[u], sz[u], pn2::norm3(sx[u], sy[u], sz[u]));
+            }
         }
         __syncthreads();
         // wave w scans the w-th contiguous quarter of this tile
