@@ -697,8 +697,9 @@ PN2_EXPORT int pn2_head_logits_dropout_backward(const float *glogp, const float 
 
 PN2_EXPORT int pn2_nll_loss_partials(long long M)
 {
-    const long long b = (M + 255) / 256;                  // one row per thread up to 65 536 rows: target -> weight -> logp is three
-                                                          // dependent loads, a second row per thread is three more round trips
+    // (256 workgroups of one row per thread were tried: 12.5 against 9.5 us -- the ticketed form ends every workgroup with
+    // a release fence, and 64 of them cost less than three more dependent round trips per thread)
+    const long long b = (M + 1023) / 1024;
     return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 

@@ -27,9 +27,10 @@ _HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "1") == "1"
 # (2.7 us of gaps in 2365 us).  With two graphs the main stream only ever waits on an event recorded one step earlier, and the
 # first level's grouped rows (25 MB) are written where the next step reads them: 2.59 -> 2.53 ms per step.
 _SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "1") == "1"
-# PN2_ALTERNATE_STEP_GRAPHS=1 (single process, with the geometry graph): two captured step graphs that read the pyramid from two
-# buffers in turn, so that the 27 MB hand-over copy disappears from the main stream
-_ALTERNATE_STEP_GRAPHS = os.environ.get("PN2_ALTERNATE_STEP_GRAPHS", "0") == "1"
+# PN2_ALTERNATE_STEP_GRAPHS (default 1; single process, with the geometry graph): two captured step graphs that read the pyramid
+# from two buffers in turn, so that the 27 MB hand-over copy (12 us) disappears from the main stream: 2.493 -> 2.480 ms per step,
+# four alternating runs each (profiles/r04/ab_alternate_step_graphs.log).  0: one step graph and the copy.
+_ALTERNATE_STEP_GRAPHS = os.environ.get("PN2_ALTERNATE_STEP_GRAPHS", "1") == "1"
 _DEFER_DW = os.environ.get("PN2_DEFER_DW", "1") != "0"    # A/B switch: 0 = every stack sums its bottom layer's slabs at once
 
 

@@ -60,7 +60,7 @@ def test_graph_and_prefetch_steps_match_eager(monkeypatch):
 
 
 # the captured step's forms: module switches of train.py (A/B evidence in DESIGN.md 6); every one that ships is run here
-STEP_FORMS = {"two graphs": {},
+STEP_FORMS = {"two graphs": {"_ALTERNATE_STEP_GRAPHS": False},
               "forked graph": {"_SEPARATE_GEOMETRY_GRAPH": False},
               "forked graph, hand-over on the side branch": {"_SEPARATE_GEOMETRY_GRAPH": False, "_HANDOVER_ON_MAIN": False},
               "alternating step graphs": {"_ALTERNATE_STEP_GRAPHS": True}}
