@@ -489,6 +489,12 @@ def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None, with_skip=False)
 
 
 # ---------------------------------------------------------------------------------- interpolation
+# PN2_LAB_SKIP_NN=<N>: lab switch -- 3-NN tables with at least N queries are computed once and then reused (WRONG results for
+# every later batch; it prices the launch for tools/ab_switch.sh, nothing else)
+_LAB_SKIP_NN = int(os.environ.get("PN2_LAB_SKIP_NN", "0"))
+_LAB_NN_CACHE = {}
+
+
 def three_nn(xyz1, xyz2, want_dist=False):
     """xyz1 [B,N,3] queries, xyz2 [B,S,3] -> idx3 [B,N,3] int64, weight3 [B,N,3] (, dist3)."""
     dev = _dev(xyz1, xyz2)
@@ -499,8 +505,15 @@ def three_nn(xyz1, xyz2, want_dist=False):
     idx3 = torch.empty((B, N, 3), dtype=torch.int64, device=dev)
     w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
     d3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if want_dist else None
+    if _LAB_SKIP_NN and not want_dist and N >= _LAB_SKIP_NN:
+        # measurement only (wrong for any batch but the first): what the table's launch costs the step beside it
+        key = (B, N, S)
+        if key in _LAB_NN_CACHE:
+            return _LAB_NN_CACHE[key]
     with torch.cuda.device(dev):
         rc = lib.pn2_three_nn(_ptr(xyz1), _ptr(xyz2), B, N, S, _ptr(idx3), _ptr(d3), _ptr(w3), _stream(dev))
+    if _LAB_SKIP_NN and not want_dist and N >= _LAB_SKIP_NN:
+        _LAB_NN_CACHE[(B, N, S)] = (idx3, w3)
     _lib.check(rc, "pn2_three_nn")
     return (idx3, w3, d3) if want_dist else (idx3, w3)
 
