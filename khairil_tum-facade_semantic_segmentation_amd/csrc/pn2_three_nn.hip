@@ -19,6 +19,17 @@ struct Top3 {
     int i0, i1, i2;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// pn2::pair_sqdist for two sources at once (v_pk_mul / v_pk_fma / v_pk_add: each half is the scalar chain, bit for bit)
+__device__ __forceinline__ f32x2 pair_sqdist2(f32x2 ax, f32x2 ay, f32x2 az, f32x2 na, f32x2 minus2, f32x2 bx, f32x2 by, f32x2 bz,
+                                             f32x2 nb)
+{
+    const f32x2 dot = __builtin_elementwise_fma(az, bz, __builtin_elementwise_fma(ay, by, ax * bx));
+    const f32x2 d = __builtin_elementwise_fma(minus2, dot, na);
+    return d + nb;
+}
+
 __device__ __forceinline__ void top3_insert(Top3 &t, float d, int j)
 {
     // strict '<': an equal distance never displaces an earlier (lower) index
@@ -35,7 +46,9 @@ __device__ __forceinline__ void three_nn_body(
     unsigned block, unsigned nblocks, const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int S, int qtiles,
     int64_t *__restrict__ idx3, float *__restrict__ dist3, float *__restrict__ weight3)
 {
-    __shared__ __attribute__((aligned(16))) float4 src[NN_TILE];
+    // sources as four arrays (x, y, z, |p|^2): four consecutive sources are one 16-byte broadcast read per array, and two
+    // of them fill the halves of a packed-fp32 operand
+    __shared__ __attribute__((aligned(16))) float srcx[NN_TILE], srcy[NN_TILE], srcz[NN_TILE], srcn[NN_TILE];
     __shared__ float md[NN_WAVES][3][PN2_WAVE];
     __shared__ int mi[NN_WAVES][3][PN2_WAVE];
 
@@ -68,17 +81,36 @@ __device__ __forceinline__ void three_nn_body(
 #pragma unroll
             for (int u = 0; u < PASSES; ++u) {
                 const int j = tid + u * NN_THREADS;
-                if (j < ns) src[j] = make_float4(sx[u], sy[u], sz[u], pn2::norm3(sx[u], sy[u], sz[u]));
+                if (j < ns) { srcx[j] = sx[u]; srcy[j] = sy[u]; srcz[j] = sz[u]; srcn[j] = pn2::norm3(sx[u], sy[u], sz[u]); }
             }
         }
         __syncthreads();
-        // wave w scans the w-th contiguous quarter of this tile
-        const int per = (ns + NN_WAVES - 1) / NN_WAVES;
-        const int jb = wave * per, je = min(ns, jb + per);
-        for (int j = jb; j < je; ++j) {
-            const float4 p = src[j];                                             // LDS broadcast
+        // wave w scans the w-th contiguous quarter of this tile (quarters start on multiples of four sources).  Four sources
+        // per pass: four broadcast reads, the four distances as two packed-fp32 chains (each component is pair_sqdist's own
+        // k-ordered fma chain: the same bits), ONE test of the smallest against the current third best -- v_min ignores a
+        // NaN as the insertion does -- and the (rare) insertions in index order.
+        const int per = ((ns + NN_WAVES - 1) / NN_WAVES + 3) & ~3;
+        const int jb = min(ns, wave * per), je = min(ns, jb + per);
+        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, na2 = {na, na}, m2 = {-2.0f, -2.0f};
+        const float4 *x4 = reinterpret_cast<const float4 *>(srcx), *y4 = reinterpret_cast<const float4 *>(srcy);
+        const float4 *z4 = reinterpret_cast<const float4 *>(srcz), *n4 = reinterpret_cast<const float4 *>(srcn);
+        int j = jb;
+        for (; j + 4 <= je; j += 4) {
+            const int q4 = j >> 2;                                               // jb is a multiple of four
+            const float4 px = x4[q4], py = y4[q4], pz = z4[q4], pn = n4[q4];     // LDS broadcasts
             // src = xyz1 (query), dst = xyz2 (source): pointnet2_utils.py:296
-            const float d = pn2::pair_sqdist(ax, ay, az, na, p.x, p.y, p.z, p.w);
+            const f32x2 dlo = pair_sqdist2(ax2, ay2, az2, na2, m2, f32x2{px.x, px.y}, f32x2{py.x, py.y}, f32x2{pz.x, pz.y}, f32x2{pn.x, pn.y});
+            const f32x2 dhi = pair_sqdist2(ax2, ay2, az2, na2, m2, f32x2{px.z, px.w}, f32x2{py.z, py.w}, f32x2{pz.z, pz.w}, f32x2{pn.z, pn.w});
+            const float least = fminf(fminf(dlo.x, dlo.y), fminf(dhi.x, dhi.y));
+            if (__ballot(least < t.d2)) {
+                top3_insert(t, dlo.x, s0 + j);
+                top3_insert(t, dlo.y, s0 + j + 1);
+                top3_insert(t, dhi.x, s0 + j + 2);
+                top3_insert(t, dhi.y, s0 + j + 3);
+            }
+        }
+        for (; j < je; ++j) {
+            const float d = pn2::pair_sqdist(ax, ay, az, na, srcx[j], srcy[j], srcz[j], srcn[j]);
             if (__ballot(d < t.d2)) top3_insert(t, d, s0 + j);
         }
     }
