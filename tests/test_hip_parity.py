@@ -166,7 +166,26 @@ def test_fps_all_points_identical(pn2, orc):
     assert np.array_equal(got, orc.farthest_point_sample(xyz, 8, start))    # all distances 0 -> index 0 forever
 
 
-@pytest.mark.parametrize("B,N,S", [(1, 5, 3), (2, 100, 3), (2, 1000, 37), (1, 70, 2500), (1, 4096, 4100)])
+def test_three_nn_ties_inside_and_across_the_groups_of_four(pn2, orc):
+    """The kernel tests four sources at a time (two packed-fp32 distance chains, one comparison of the smallest with the third
+    best) and a wave's range of sources starts on a multiple of four.  Sources on a small integer lattice, listed twice: every
+    query has exact ties inside a group of four, across groups, across the four waves' ranges and between the two copies --
+    indices and distances are the oracle's bit for bit (lowest index first)."""
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rs = np.random.RandomState(4)
+    for S in (197, 200, 203):
+        src = np.concatenate([g, g])[rs.permutation(200)][None][:, :min(S, 200)]
+        if S > 200:
+            src = np.concatenate([src, src[:, :S - 200]], 1)
+        q = np.concatenate([g[:64] + 0.5, g[:64], rs.uniform(0, 4, (64, 3)).astype(np.float32)])[None].astype(np.float32)
+        idx3, w3, d3 = pn2.ops.three_nn(dev(pn2, q), dev(pn2, src), want_dist=True)
+        oi, od, ow = orc.three_nn(q, src)
+        assert np.array_equal(host(idx3), oi), S
+        assert np.array_equal(host(d3), od), S
+
+
+@pytest.mark.parametrize("B,N,S", [(1, 5, 3), (2, 100, 3), (1, 33, 5), (1, 64, 6), (2, 65, 7), (2, 1000, 37), (1, 300, 129),
+                                   (1, 128, 1023), (1, 70, 2500), (1, 4096, 4100)])
 def test_three_nn_ragged_shapes(pn2, orc, B, N, S):
     rs = np.random.RandomState(N + S)
     xyz1 = rs.normal(size=(B, N, 3)).astype(np.float32)
