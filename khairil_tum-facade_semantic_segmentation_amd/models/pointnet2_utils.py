@@ -159,6 +159,12 @@ class PointNetSetAbstraction(nn.Module):                # reference :161-202
         points [B,N,D] (features that need no gradient -- the network input): a third result, the grouped rows
         [B,S,K,pad4(3+D)] from the SAME launch that finds the indices (the planned query gathers them from the plan's
         packed rows); None when the shape is outside the planned path."""
+        if "deep" in ops._LAB_SKIP and points is None and not getattr(self, "_lab_inside", False):
+            self._lab_inside = True                      # lab switch (ops.lab_cached): levels without input rows, computed once
+            try:
+                return ops.lab_cached("deep", (tuple(xyz.shape), self.npoint), lambda: self.geometry(xyz, start))
+            finally:
+                self._lab_inside = False
         if start is None:
             start = _next_start(xyz.device)
         B, N, _ = xyz.shape

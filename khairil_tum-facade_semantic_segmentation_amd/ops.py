@@ -311,6 +311,12 @@ def invert_index(idx, nkeys):
     """Transposed index table of idx [B, ...] with values in [0, nkeys): (offsets [B,nkeys+1] int32,
     entries [B,E] int32) for the gather-sum form of the backward passes, or None when the table is too
     large for the on-chip transposition (the scatter-add operators are used then)."""
+    if "inv" in _LAB_SKIP and not getattr(invert_index, "_inside", False):
+        invert_index._inside = True
+        try:
+            return lab_cached("inv", (tuple(idx.shape), int(nkeys)), lambda: invert_index(idx, nkeys))
+        finally:
+            invert_index._inside = False
     dev = _dev(idx)
     lib = _lib.load()
     idx = _i64c(idx)
@@ -490,9 +496,22 @@ def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None, with_skip=False)
 
 # ---------------------------------------------------------------------------------- interpolation
 # PN2_LAB_SKIP_NN=<N>: lab switch -- 3-NN tables with at least N queries are computed once and then reused (WRONG results for
-# every later batch; it prices the launch for tools/ab_switch.sh, nothing else)
+# every later batch; it prices the launch for tools/ab_switch.sh, nothing else).  PN2_LAB_SKIP=inv,deep: the same for the
+# transposed index tables and for the sampling + ball queries of levels 2-4 (models/pointnet2_utils.py).
 _LAB_SKIP_NN = int(os.environ.get("PN2_LAB_SKIP_NN", "0"))
 _LAB_NN_CACHE = {}
+_LAB_SKIP = set(t for t in os.environ.get("PN2_LAB_SKIP", "").split(",") if t)
+_LAB_CACHE = {}
+
+
+def lab_cached(tag, key, fn):
+    """fn() -- or, with `tag` in PN2_LAB_SKIP, what fn() returned the first time it was called with this key."""
+    if tag not in _LAB_SKIP:
+        return fn()
+    k = (tag,) + tuple(key)
+    if k not in _LAB_CACHE:
+        _LAB_CACHE[k] = fn()
+    return _LAB_CACHE[k]
 
 
 def three_nn(xyz1, xyz2, want_dist=False):
