@@ -320,6 +320,8 @@ def main():
     filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     model = model.to(dev)
+    if os.environ.get("PN2_LAB_MAIN_HIGH_PRIORITY", "0") == "1":      # lab: the step on a high-priority HIP stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     trainer = SemSegTrainer(model, class_weight=torch.ones(NUM_CLASSES, device=dev), graphs=not args.no_graphs,
                             prefetch_geometry=not args.no_prefetch)
     if use_dist and not args.no_graphs:

@@ -144,10 +144,48 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
     }
 }
 
+// LAB kernel (PN2_TUNE_lab_fps_dummy=<microseconds>, N >= 4096 only; wrong results by design): the footprint of
+// fps_kernel<512,8> -- 512 threads, 64 registers per lane, its dynamic LDS -- held for the given time by sleeping waves, with the
+// block's first npoint points handed out as "centroids".  It separates what the sampling kernel costs the step beside it by
+// OCCUPYING 16 CUs from what its instructions cost.  0 us: the footprint for an instant.
+template <bool REGS>
+__global__ __launch_bounds__(512) void fps_dummy_kernel(const float *__restrict__ xyz, int N, int npoint, int64_t *__restrict__ out_idx,
+                                                        float *__restrict__ new_xyz, int hold_us)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (REGS) asm volatile("v_mov_b32 v63, 0" ::: "v63");            // the register allocation of the real kernel
+    if (tid == 0) smem[0] = 0;
+    for (int i = tid; i < npoint; i += (int)blockDim.x) {
+        const int j = i < N ? i : N - 1;
+        if (out_idx) out_idx[(size_t)b * npoint + i] = j;
+        if (new_xyz)
+            for (int c = 0; c < 3; ++c) new_xyz[((size_t)b * npoint + i) * 3 + c] = xyz[((size_t)b * N + j) * 3 + c];
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)hold_us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
+
 template <int T, int P>
 int launch_fps(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out_idx,
                float *new_xyz, int32_t *err_count, hipStream_t stream)
 {
+    if (T == 512 && P == 8) {
+        const int hold = pn2::tune_get("lab_fps_dummy", -1);
+        if (hold >= 0) {
+            // which part of the footprint: PN2_TUNE_lab_fps_dummy_lds (bytes, default the kernel's 64 KB), _threads (512), _regs (1)
+            const size_t lds = (size_t)pn2::tune_get("lab_fps_dummy_lds", (int)(2 * 16 * sizeof(unsigned long long) + (size_t)T * P * sizeof(float4)));
+            const int threads = pn2::tune_get("lab_fps_dummy_threads", 512);
+            static pn2::PerDevice memo, memo2;
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(fps_dummy_kernel<true>), 160 * 1024, memo)) return e;
+            if (const int e = pn2::ensure_dynamic_lds(reinterpret_cast<const void *>(fps_dummy_kernel<false>), 160 * 1024, memo2)) return e;
+            if (pn2::tune_get("lab_fps_dummy_regs", 1))
+                hipLaunchKernelGGL(fps_dummy_kernel<true>, dim3(B), dim3(threads), lds, stream, xyz, N, npoint, out_idx, new_xyz, hold);
+            else
+                hipLaunchKernelGGL(fps_dummy_kernel<false>, dim3(B), dim3(threads), lds, stream, xyz, N, npoint, out_idx, new_xyz, hold);
+            return PN2_LAUNCH_RC();
+        }
+    }
     const size_t slots = 2 * 16 * sizeof(unsigned long long);
     const bool lds_xyz = (size_t)T * P * sizeof(float4) <= 128 * 1024;
     if (lds_xyz) {

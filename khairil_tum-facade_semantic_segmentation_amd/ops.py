@@ -252,6 +252,12 @@ def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, p
     # No plan given: the self-contained entry (one launch).  Building a plan for ONE query costs more than it saves
     # (SA1, B = 16: plan 11.5 us + planned query 8.9 us against 19.3 us self-contained) -- a plan pays
     # for callers that reuse it, who build it with ball_plan() / farthest_point_sample_plan() and pass it in.
+    if plan is not None and want_grouped and "q1" in _LAB_SKIP:
+        # lab switch (wrong results): the planned query of a shape is launched once, later calls return its indices and leave
+        # the rows buffer as it is -- what the row packing + query launches cost the step beside them
+        key = ("q1", B, N, S, nsample, ldg)
+        if key in _LAB_CACHE:
+            return _LAB_CACHE[key], grouped
     if plan is not None:
         if want_grouped and ldg == 3 + D and (3 + D) % 4 == 0:
             plan.pack_rows(xyz, points)                       # the fused row stores gather from the plan's packed rows
@@ -266,6 +272,8 @@ def _ball_query_group_raw(radius, nsample, xyz, new_xyz, points, want_grouped, p
                                           D, _ptr(idx), _ptr(grouped), ldg, _ptr(_err_word(dev)), _stream(dev))
         _lib.check(rc, "pn2_ball_query_group")
     _after_fault_op(dev, "query_ball_point")
+    if plan is not None and want_grouped and "q1" in _LAB_SKIP:
+        _LAB_CACHE[("q1", B, N, S, nsample, ldg)] = idx
     return idx, grouped
 
 

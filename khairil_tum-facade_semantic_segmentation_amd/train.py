@@ -27,6 +27,11 @@ _HANDOVER_ON_MAIN = os.environ.get("PN2_HANDOVER_ON_MAIN", "1") == "1"
 # (2.7 us of gaps in 2365 us).  With two graphs the main stream only ever waits on an event recorded one step earlier, and the
 # first level's grouped rows (25 MB) are written where the next step reads them: 2.59 -> 2.53 ms per step.
 _SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "1") == "1"
+# PN2_LATE_SIDE_ENQUEUE=0: the geometry graph is enqueued ahead of the step's graph behind a cross-stream wait (the form of
+# rounds 3 / early 4) instead of behind a host wait for the previous step's graph (SemSegTrainer._enqueue_geometry)
+_LATE_SIDE_ENQUEUE = os.environ.get("PN2_LATE_SIDE_ENQUEUE", "1") == "1"
+# lab (wrong results): the geometry graph is captured but never replayed -- the step graphs in their shipped form, alone
+_LAB_NO_SIDE_REPLAY = os.environ.get("PN2_LAB_NO_SIDE_REPLAY", "0") == "1"
 # PN2_ALTERNATE_STEP_GRAPHS (default 1; single process, with the geometry graph): two captured step graphs that read the pyramid
 # from two buffers in turn, so that the 27 MB hand-over copy (12 us) disappears from the main stream: 2.493 -> 2.480 ms per step,
 # four alternating runs each (profiles/r04/ab_alternate_step_graphs.log).  0: one step graph and the copy.
@@ -259,7 +264,8 @@ class SemSegTrainer:
             from .ops import SegMetrics
             ncls = model.conv2.out_channels if hasattr(model, "conv2") else int(metrics)
             self.metrics = SegMetrics(ncls, next(model.parameters()).device)
-        self._side = torch.cuda.Stream() if self.prefetch else None
+        # PN2_SIDE_STREAM_PRIORITY: HIP priority of the geometry stream (0 = default = the main stream's; larger = lower)
+        self._side = torch.cuda.Stream(priority=int(os.environ.get("PN2_SIDE_STREAM_PRIORITY", "0"))) if self.prefetch else None
         self._prepares = hasattr(model, "prepare_input")        # the pyramid hands the prepared input rows over too
         self._unit = torch.ones((), dtype=torch.float32, device=next(model.parameters()).device) if on_gpu else None
         self._geo_next = None            # pyramid computed for the coming step
@@ -512,6 +518,8 @@ class SemSegTrainer:
             # graph then has ONE branch and stays on the stream it is launched on (see _SEPARATE_GEOMETRY_GRAPH)
             self._geo_next_flat = self._geo_flat.clone()
             self._geo_ready = torch.cuda.Event()
+            self._inputs_ready = torch.cuda.Event()
+            self._step_ends, self._step_end, self._step_parity = [torch.cuda.Event(), torch.cuda.Event()], None, 0
             self._side.wait_stream(torch.cuda.current_stream())
             self._g_geo = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_geo, stream=self._side):     # a pool of its own: the two graphs run side by side
@@ -574,6 +582,32 @@ class SemSegTrainer:
             with torch.cuda.graph(self._g_opt, pool=pool):
                 self.flat_adam.step(flat, 1.0 / self._world())
 
+    def _enqueue_geometry(self, graph, nxt):
+        """The side stream's work of this step (the next batch's pyramid), enqueued BEHIND the step's graph.
+        The geometry graph may not start before the PREVIOUS step's graph has finished (that graph reads the pyramid buffer
+        this one fills).  Enqueued ahead of time behind a cross-stream wait, that dependency sits at the head of the side
+        queue as an unsatisfied barrier for as long as the host runs ahead of the GPU -- and a step graph runs 95 us longer
+        beside a queue that is blocked like that (tools/step_events.py: 2.395 against 2.300 ms with nothing at all running on
+        the side stream).  So the host waits here until the previous step's graph has finished, then enqueues: nothing is
+        ever pending on the side queue.  The GPU does not starve -- this step's graph is already queued -- and the host stays
+        at most one step ahead; a caller who synchronises every step never waits here."""
+        main = torch.cuda.current_stream()
+        if _LATE_SIDE_ENQUEUE:
+            prev, self._step_end = self._step_end, self._step_ends[self._step_parity]
+            self._step_parity ^= 1
+            self._step_end.record(main)                         # this step's graph is in the queue up to here
+            if prev is not None:
+                prev.synchronize()                              # host: the previous step's graph has finished
+            self._side.wait_event(self._inputs_ready)           # (fires at once: it sits in front of this step's graph)
+            with torch.cuda.stream(self._side):
+                self._static_next_x.copy_(nxt)
+            if nxt.is_cuda:
+                nxt.record_stream(self._side)                   # the caller may free it while the side stream still reads it
+        with torch.cuda.stream(self._side):
+            if not _LAB_NO_SIDE_REPLAY:
+                graph.replay()
+            self._geo_ready.record()
+
     def step(self, blocks_cf, target, next_blocks_cf=None):
         """blocks_cf [B,C,N] (channel-first like the reference loop, localfunctions.py:209),
         target [B,N] int64; next_blocks_cf (optional, with prefetch_geometry) is the batch the
@@ -617,7 +651,7 @@ class SemSegTrainer:
                 self._geo_flat.copy_(self._geo_next_flat)    # the pyramid the side graph left for this batch
             nxt = blocks_cf if next_blocks_cf is None else next_blocks_cf
             self._geo_next_src = self._identity(nxt)
-            if self._g_geo is not None:
+            if self._g_geo is not None and not _LATE_SIDE_ENQUEUE:
                 # the next input is copied on the SIDE stream, in front of the graph that reads it (the previous replay of that
                 # graph, the buffer's only other reader, is ahead of it on the same stream): 2.4 MB less on the main stream
                 self._side.wait_stream(main)                    # `nxt` is ready, the second pyramid buffer is free
@@ -625,6 +659,8 @@ class SemSegTrainer:
                     self._static_next_x.copy_(nxt)
                 if nxt.is_cuda:
                     nxt.record_stream(self._side)               # the caller may free it while the side stream still reads it
+            elif self._g_geo is not None:
+                self._inputs_ready.record(main)                 # `nxt` and the fix-ups above are in the main queue up to here
             else:
                 self._static_next_x.copy_(nxt)
         if self.prefetch and self._tap is not None:
@@ -634,17 +670,13 @@ class SemSegTrainer:
             alt = self._alt
             p = alt["p"]
             alt["main"][p].replay()                             # reads pyramid buffer p
-            with torch.cuda.stream(self._side):
-                alt["geo"][p].replay()                          # fills buffer 1 - p for the next step
-                self._geo_ready.record()
+            self._enqueue_geometry(alt["geo"][p], nxt)          # fills buffer 1 - p for the next step
             self._static_loss = alt["loss"][p]
             alt["p"] = p ^ 1
         else:
             self._g_fwd_bwd.replay()
             if self.prefetch and self._g_geo is not None:
-                with torch.cuda.stream(self._side):
-                    self._g_geo.replay()
-                    self._geo_ready.record()
+                self._enqueue_geometry(self._g_geo, nxt)
         if self._g_opt is not None:
             dist.all_reduce(self.grads.buffer, op=dist.ReduceOp.SUM, group=self.group)
             self._g_opt.replay()
