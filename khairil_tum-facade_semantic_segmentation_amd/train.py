@@ -30,6 +30,9 @@ _SEPARATE_GEOMETRY_GRAPH = os.environ.get("PN2_SEPARATE_GEOMETRY_GRAPH", "1") ==
 # PN2_LATE_SIDE_ENQUEUE=0: the geometry graph is enqueued ahead of the step's graph behind a cross-stream wait (the form of
 # rounds 3 / early 4) instead of behind a host wait for the previous step's graph (SemSegTrainer._enqueue_geometry)
 _LATE_SIDE_ENQUEUE = os.environ.get("PN2_LATE_SIDE_ENQUEUE", "1") == "1"
+# PN2_PACK_IN_PLACE=0: the pyramid's small tensors are concatenated into a temporary and copied (two launches per part) instead of
+# concatenated straight into the pyramid buffer
+_PACK_IN_PLACE = os.environ.get("PN2_PACK_IN_PLACE", "1") == "1"
 # lab (wrong results): the geometry graph is captured but never replayed -- the step graphs in their shipped form, alone
 _LAB_NO_SIDE_REPLAY = os.environ.get("PN2_LAB_NO_SIDE_REPLAY", "0") == "1"
 # PN2_ALTERNATE_STEP_GRAPHS (default 1; single process, with the geometry graph): two captured step graphs that read the pyramid
@@ -54,19 +57,29 @@ def rotate_z_(blocks_cf, angles=None):
     return blocks_cf
 
 
-def pack_segments(tensors, pads):
+def pack_segments(tensors, pads, out=None):
     """The tensors (None = absent) with their zero pads (uint8, None = none) as one uint8 buffer.  Concatenated as
     32-bit words when every segment allows it: torch's byte-wise cat moves one byte per thread (110 us for the 27 MB of
-    a pyramid with the first level's grouped rows; 4x fewer elements this way)."""
+    a pyramid with the first level's grouped rows; 4x fewer elements this way).  out (uint8, exactly the packed size):
+    the concatenation is written there by the cat kernel itself -- no packed temporary and no copy of it."""
     parts = []
     for t, pad in zip(tensors, pads):
         if t is not None:
             parts.append(t.contiguous().view(-1).view(torch.uint8))
         if pad is not None:
             parts.append(pad)
-    if all(p.numel() % 4 == 0 and p.data_ptr() % 4 == 0 for p in parts):
-        return torch.cat([p.view(torch.int32) for p in parts]).view(torch.uint8)
-    return torch.cat(parts)
+    words = all(p.numel() % 4 == 0 and p.data_ptr() % 4 == 0 for p in parts)
+    if out is not None and _PACK_IN_PLACE and out.numel() == sum(p.numel() for p in parts) and out.is_contiguous():
+        if words and out.data_ptr() % 4 == 0:
+            torch.cat([p.view(torch.int32) for p in parts], out=out.view(torch.int32))
+        else:
+            torch.cat(parts, out=out)
+        return out
+    packed = torch.cat([p.view(torch.int32) for p in parts]).view(torch.uint8) if words else torch.cat(parts)
+    if out is not None:
+        out.copy_(packed)
+        return out
+    return packed
 
 
 class FlatGradients:
@@ -398,9 +411,9 @@ class SemSegTrainer:
             ops.place_next_grouped(None)                    # an offer nobody took must not reach an unrelated call
         if placeable and geo[big] is not None and geo[big].data_ptr() == view.data_ptr():
             if big > 0:
-                flat[:o0].copy_(pack_segments(geo[:big], self._geo_pads[:big]))
+                pack_segments(geo[:big], self._geo_pads[:big], out=flat[:o0])
             if big + 1 < len(geo):
-                flat[o1:].copy_(pack_segments(geo[big + 1:], self._geo_pads[big + 1:]))
+                pack_segments(geo[big + 1:], self._geo_pads[big + 1:], out=flat[o1:])
             if pad:
                 flat[o1 - pad:o1].zero_()
         else:
