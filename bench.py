@@ -324,8 +324,11 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     trainer = SemSegTrainer(model, class_weight=torch.ones(NUM_CLASSES, device=dev), graphs=not args.no_graphs,
                             prefetch_geometry=not args.no_prefetch)
-    if use_dist and not args.no_graphs:
-        trainer.prepare(x, y)            # capture before the first collective creates the RCCL communicator
+    if not args.no_graphs:
+        # capture now (setup, not a step): before the first collective creates the RCCL communicator, and so that the warm-up
+        # steps below are REPLAYS -- the first launch of a graph uploads it (0.3-0.5 ms once per graph: the two alternating step
+        # graphs and their geometry graphs would otherwise see their first launch inside the K timed steps)
+        trainer.prepare(x, y)
     trainer.broadcast_parameters()
 
     def barrier():
@@ -333,7 +336,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 5 if not args.no_graphs else 0)):   # >= 3 eager + capture + 1 replay before timing
+    for _ in range(max(args.warmup, 4 if not args.no_graphs else 0)):   # every graph replayed at least twice before timing
         trainer.step(x, y)
     barrier()
     t0 = time.perf_counter()
