@@ -474,6 +474,9 @@ def shard_batches(num_blocks, batch_size, rank=0, world=1):
 
 # PN2_INFER_TWO_GRAPHS=0: the forked single graph of rounds 1-2 (the pyramid of the next sub-batch as a branch of the forward's graph)
 _TWO_GRAPHS = os.environ.get("PN2_INFER_TWO_GRAPHS", "1") == "1"
+# PN2_INFER_LATE_SIDE_ENQUEUE=0: the next sub-batch's geometry graph is enqueued ahead of the forward behind a cross-stream wait
+# instead of behind the forward and a host wait for the previous one (BlockInferencer.run)
+_LATE_SIDE_ENQUEUE = os.environ.get("PN2_INFER_LATE_SIDE_ENQUEUE", "1") == "1"
 
 
 class BlockInferencer:
@@ -572,7 +575,8 @@ class BlockInferencer:
                     fpool = g.pool()
                     fwds.append(g)
                     logps.append(logp)
-                self._two = {"geo": geos, "fwd": fwds, "logp": logps, "bufs": bufs, "p": 0, "ready": torch.cuda.Event()}
+                self._two = {"geo": geos, "fwd": fwds, "logp": logps, "bufs": bufs, "p": 0, "ready": torch.cuda.Event(),
+                             "inputs": torch.cuda.Event(), "ends": [torch.cuda.Event(), torch.cuda.Event()]}
                 self._graph = fwds[0]
                 self.logp = logps[0]
                 return
@@ -622,6 +626,7 @@ class BlockInferencer:
                 main.wait_event(two["ready"])                     # (a geometry graph of an earlier run)
             load(self.next_x, batches[0])
             (self._flat if two is None else two["bufs"][two["p"]]).copy_(self._pack(self._geometry_of(self.next_x)))   # the first pyramid
+            prev_end = None
             for i, blocks in enumerate(batches):
                 nxt = batches[i + 1] if i + 1 < len(batches) else blocks
                 b = blocks.shape[0]
@@ -633,12 +638,30 @@ class BlockInferencer:
                 p = two["p"]
                 if i > 0:
                     main.wait_event(two["ready"])                 # the side graph has read next_x and filled buffer p
-                load(self.next_x, nxt)
-                self._side.wait_stream(main)
-                two["fwd"][p].replay()                            # reads pyramid buffer p
-                with torch.cuda.stream(self._side):
-                    two["geo"][p].replay()                        # the pyramid of next_x into buffer 1 - p
-                    two["ready"].record()
+                if not _LATE_SIDE_ENQUEUE:
+                    load(self.next_x, nxt)
+                    self._side.wait_stream(main)
+                    two["fwd"][p].replay()                        # reads pyramid buffer p
+                    with torch.cuda.stream(self._side):
+                        two["geo"][p].replay()                    # the pyramid of next_x into buffer 1 - p
+                        two["ready"].record()
+                else:
+                    # the side stream's work is enqueued BEHIND this forward and after a host wait for the previous one: its
+                    # dependency (the previous forward read the buffer it fills) is then satisfied when it is enqueued, and the
+                    # side queue never sits blocked at a cross-stream barrier -- a graph runs measurably longer beside a queue
+                    # that does (train.SemSegTrainer._enqueue_geometry)
+                    two["inputs"].record(main)                    # whatever produced `nxt` is in the main queue up to here
+                    two["fwd"][p].replay()                        # reads pyramid buffer p
+                    end = two["ends"][i & 1]
+                    end.record(main)
+                    if prev_end is not None:
+                        prev_end.synchronize()
+                    prev_end = end
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(two["inputs"])
+                        load(self.next_x, nxt)
+                        two["geo"][p].replay()                    # the pyramid of next_x into buffer 1 - p
+                        two["ready"].record()
                 self.logp = two["logp"][p]
                 consume(i, self.logp[:b])
                 two["p"] = p ^ 1
