@@ -474,6 +474,8 @@ def shard_batches(num_blocks, batch_size, rank=0, world=1):
 
 # PN2_INFER_TWO_GRAPHS=0: the forked single graph of rounds 1-2 (the pyramid of the next sub-batch as a branch of the forward's graph)
 _TWO_GRAPHS = os.environ.get("PN2_INFER_TWO_GRAPHS", "1") == "1"
+# PN2_INFER_PLACE=0: the geometry graph packs the whole pyramid into a temporary and copies it into the static buffer
+_PLACE = os.environ.get("PN2_INFER_PLACE", "1") == "1"
 # PN2_INFER_LATE_SIDE_ENQUEUE=0: the next sub-batch's geometry graph is enqueued ahead of the forward behind a cross-stream wait
 # instead of behind the forward and a host wait for the previous one (BlockInferencer.run)
 _LATE_SIDE_ENQUEUE = os.environ.get("PN2_INFER_LATE_SIDE_ENQUEUE", "1") == "1"
@@ -515,6 +517,36 @@ class BlockInferencer:
     def _pack(self, geo):
         from .train import pack_segments
         return pack_segments(geo, self._pads)
+
+    def _fill(self, flat, views):
+        """The pyramid of `next_x` into the static buffer `flat` (whose tensor views are `views`): the first level's grouped rows
+        -- nearly all of its bytes -- are written by the query launch itself (ops.place_next_grouped), the small tensors in front
+        of and behind them are concatenated straight into the buffer (train.pack_segments(out=...)): no packed temporary of
+        the whole pyramid and no copy of it (PN2_INFER_PLACE=0: both, as before)."""
+        from . import ops
+        from .train import pack_segments
+        sizes = [0 if v is None else v.numel() * v.element_size() for v in views]
+        big = max(range(len(views)), key=lambda i: sizes[i])
+        view = views[big]
+        placeable = _PLACE and view is not None and view.dtype == self.torch.float32 and view.dim() == 4
+        if placeable:
+            ops.place_next_grouped(view)
+        try:
+            geo = self._geometry_of(self.next_x)
+        finally:
+            ops.place_next_grouped(None)                          # an offer nobody took must not reach an unrelated call
+        if placeable and geo[big] is not None and geo[big].data_ptr() == view.data_ptr():
+            o0 = view.data_ptr() - flat.data_ptr()
+            pad = 0 if self._pads[big] is None else self._pads[big].numel()
+            o1 = o0 + sizes[big] + pad
+            if big > 0:
+                pack_segments(geo[:big], self._pads[:big], out=flat[:o0])
+            if big + 1 < len(geo):
+                pack_segments(geo[big + 1:], self._pads[big + 1:], out=flat[o1:])
+            if pad:
+                flat[o1 - pad:o1].zero_()
+        else:
+            flat.copy_(self._pack(geo))
 
     def _capture(self):
         torch = self.torch
@@ -562,7 +594,7 @@ class BlockInferencer:
                     self._side.wait_stream(main)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=self._side, **({} if gpool is None else {"pool": gpool})):
-                        bufs[1 - p].copy_(self._pack(self._geometry_of(self.next_x)))      # fills the OTHER buffer
+                        self._fill(bufs[1 - p], views[1 - p])                              # fills the OTHER buffer
                     gpool = g.pool()
                     main.wait_stream(self._side)
                     torch.cuda.synchronize(self.dev)

@@ -625,7 +625,8 @@ class SemSegTrainer:
         """blocks_cf [B,C,N] (channel-first like the reference loop, localfunctions.py:209),
         target [B,N] int64; next_blocks_cf (optional, with prefetch_geometry) is the batch the
         NEXT call will train on (default: the same batch again).  Returns the (rank-local) loss
-        tensor, no host sync."""
+        tensor.  No host synchronisation with THIS step; with the geometry graph the call returns once the PREVIOUS
+        step's graph has finished (_enqueue_geometry: the host stays at most one step ahead of the GPU)."""
         self.model.train()
         mlp.invalidate_eval_coefficients()                 # a replayed graph rewrites weights and running statistics
         if not self.graphs:

@@ -63,7 +63,9 @@ def test_graph_and_prefetch_steps_match_eager(monkeypatch):
 STEP_FORMS = {"two graphs": {"_ALTERNATE_STEP_GRAPHS": False},
               "forked graph": {"_SEPARATE_GEOMETRY_GRAPH": False},
               "forked graph, hand-over on the side branch": {"_SEPARATE_GEOMETRY_GRAPH": False, "_HANDOVER_ON_MAIN": False},
-              "alternating step graphs": {"_ALTERNATE_STEP_GRAPHS": True}}
+              "alternating step graphs": {"_ALTERNATE_STEP_GRAPHS": True},
+              "geometry graph enqueued ahead, behind a cross-stream wait": {"_LATE_SIDE_ENQUEUE": False},
+              "small tensors packed through a temporary": {"_PACK_IN_PLACE": False}}
 
 
 @pytest.mark.parametrize("form", sorted(STEP_FORMS))
@@ -71,7 +73,7 @@ def test_every_replay_reads_the_pyramid_of_the_batch_it_trains_on(monkeypatch, f
     """Graph + prefetch on alternating cube / facade batches: the pyramid tensors a replay is about to read (cloned by a
     hook right in front of it) equal compute_geometry() of THAT batch bit for bit -- the prefetched one when the batch was
     announced, a freshly computed one when it was not (a step on another batch than the one announced; the same batch
-    twice in a row).  A stale or foreign pyramid cannot hide behind a loss tolerance here.  All four forms of the step."""
+    twice in a row).  A stale or foreign pyramid cannot hide behind a loss tolerance here.  Every form of the step that ships behind a switch."""
     torch, xs, ys, cw, fresh_model = _setup(monkeypatch)
     from khairil_tum_facade_semantic_segmentation_amd import train as T
     for k, v in STEP_FORMS[form].items():
@@ -91,7 +93,9 @@ def test_every_replay_reads_the_pyramid_of_the_batch_it_trains_on(monkeypatch, f
     for b, nxt in plan:
         losses.append(tr.step(xs[b], ys[b], None if nxt is None else xs[nxt]))
     torch.cuda.synchronize()
-    assert (tr._alt is not None) == (form == "alternating step graphs") and (tr._g_geo is not None) == (not form.startswith("forked"))
+    forked = form.startswith("forked")
+    assert (tr._alt is not None) == (not forked and STEP_FORMS[form].get("_ALTERNATE_STEP_GRAPHS", True))
+    assert (tr._g_geo is not None) == (not forked)
     assert len(taps) == len(plan)
     for i, ((b, _), read) in enumerate(zip(plan, taps)):
         assert len(read) == len(want[b])
