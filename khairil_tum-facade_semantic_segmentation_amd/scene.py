@@ -507,6 +507,14 @@ class BlockInferencer:
         self._captured_ptrs = None
         self.logp = None
 
+    def __del__(self):
+        # a captured graph must not be destroyed while a replay of it is still running (the geometry graph runs on the side
+        # stream, behind the caller's back): wait for the device before the graphs go
+        try:
+            self.torch.cuda.synchronize(self.dev)
+        except Exception:
+            pass
+
     def _param_ptrs(self):
         return [t.data_ptr() for t in list(self.model.parameters()) + list(self.model.buffers())]
 
@@ -689,11 +697,12 @@ class BlockInferencer:
                     if prev_end is not None:
                         prev_end.synchronize()
                     prev_end = end
-                    with torch.cuda.stream(self._side):
-                        self._side.wait_event(two["inputs"])
-                        load(self.next_x, nxt)
-                        two["geo"][p].replay()                    # the pyramid of next_x into buffer 1 - p
-                        two["ready"].record()
+                    if i + 1 < len(batches):                      # (no pyramid behind the last sub-batch: nothing stays in flight)
+                        with torch.cuda.stream(self._side):
+                            self._side.wait_event(two["inputs"])
+                            load(self.next_x, nxt)
+                            two["geo"][p].replay()                # the pyramid of next_x into buffer 1 - p
+                            two["ready"].record()
                 self.logp = two["logp"][p]
                 consume(i, self.logp[:b])
                 two["p"] = p ^ 1

@@ -300,6 +300,15 @@ class SemSegTrainer:
         for t in list(self.model.parameters()) + list(self.model.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
 
+    def __del__(self):
+        # a captured graph must not be destroyed while a replay of it is still running: the geometry graph of the last step
+        # runs on the side stream for about a millisecond after step() has returned -- wait for the device before the graphs go
+        try:
+            if self._g_fwd_bwd is not None:
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
     def prepare(self, blocks_cf, target):
         """Capture the hipGraphs NOW, without changing the model: `graph_warmup` dry forward/backward
         passes (allocator and lazy initialisations settle; BatchNorm buffers are restored afterwards, no
