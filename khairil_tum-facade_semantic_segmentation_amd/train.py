@@ -35,6 +35,7 @@ _LATE_SIDE_ENQUEUE = os.environ.get("PN2_LATE_SIDE_ENQUEUE", "1") == "1"
 _PACK_IN_PLACE = os.environ.get("PN2_PACK_IN_PLACE", "1") == "1"
 # lab (wrong results): the geometry graph is captured but never replayed -- the step graphs in their shipped form, alone
 _LAB_NO_SIDE_REPLAY = os.environ.get("PN2_LAB_NO_SIDE_REPLAY", "0") == "1"
+_LAB_SIDE_DELAY = int(os.environ.get("PN2_LAB_SIDE_DELAY_US", "0"))         # lab: the host enqueues the geometry graph this much later
 # PN2_ALTERNATE_STEP_GRAPHS (default 1; single process, with the geometry graph): two captured step graphs that read the pyramid
 # from two buffers in turn, so that the 27 MB hand-over copy (12 us) disappears from the main stream: 2.493 -> 2.480 ms per step,
 # four alternating runs each (profiles/r04/ab_alternate_step_graphs.log).  0: one step graph and the copy.
@@ -620,6 +621,11 @@ class SemSegTrainer:
             self._step_end.record(main)                         # this step's graph is in the queue up to here
             if prev is not None:
                 prev.synchronize()                              # host: the previous step's graph has finished
+                if _LAB_SIDE_DELAY:                             # lab: the geometry graph starts this many us into the step
+                    import time
+                    t_end = time.perf_counter() + _LAB_SIDE_DELAY * 1e-6
+                    while time.perf_counter() < t_end:
+                        pass
             self._side.wait_event(self._inputs_ready)           # (fires at once: it sits in front of this step's graph)
             with torch.cuda.stream(self._side):
                 self._static_next_x.copy_(nxt)
