@@ -225,6 +225,8 @@ PN2_EXPORT int pn2_farthest_point_sample(const float *xyz, int B, int N, int npo
     PN2_FPS_CASE(128, 4);
     PN2_FPS_CASE(256, 4);
     PN2_FPS_CASE(512, 4);
+    // (N <= 4096 as 256 threads x 16 points -- one wave per SIMD -- and as 1024 x 4 -- four per SIMD -- measured: 599 / 593 us
+    // against 550 us for 512 x 8)
     PN2_FPS_CASE(512, 8);
     PN2_FPS_CASE(1024, 8);
     PN2_FPS_CASE(1024, 16);
