@@ -29,6 +29,17 @@ def test_pack_segments_word_and_byte_paths():
     odd = [torch.arange(3, dtype=torch.uint8), torch.randn(4, generator=g)]
     flat2 = pack_segments(odd, [None, None])
     assert torch.equal(flat2[:3], odd[0]) and torch.equal(flat2[3:].clone().view(torch.float32), odd[1])
+    # out=: the concatenation is written straight into the caller's buffer (a slice of a bigger one), word and byte paths;
+    # a buffer of another size is refused by copy_ -- never written past its end
+    big = torch.full((flat.numel() + 32,), 0xAA, dtype=torch.uint8)
+    got = pack_segments(tensors, pads, out=big[16:16 + flat.numel()])
+    assert got.data_ptr() == big[16:].data_ptr() and torch.equal(got, flat)
+    assert (big[:16] == 0xAA).all() and (big[16 + flat.numel():] == 0xAA).all()
+    big2 = torch.zeros(flat2.numel() + 5, dtype=torch.uint8)
+    assert torch.equal(pack_segments(odd, [None, None], out=big2[5:]), flat2)          # unaligned target: byte path
+    import pytest
+    with pytest.raises(RuntimeError):
+        pack_segments(tensors, pads, out=torch.zeros(flat.numel() + 16, dtype=torch.uint8))
 
 
 def test_batch_plan_is_rank_dependent_and_size_proportional():
