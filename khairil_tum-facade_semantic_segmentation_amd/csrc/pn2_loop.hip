@@ -28,12 +28,25 @@ __global__ __launch_bounds__(256) void input_blocks_kernel(const float *__restri
     if (angles) { const float a = angles[b]; c = cosf(a); s = sinf(a); }
     float *o = pts + (size_t)t * C;
     float x = 0.f, y = 0.f, z = 0.f;
-    for (int k = 0; k < C; ++k) {
-        const float v = channel_first ? src[(size_t)k * N + n] : src[(size_t)n * C + k];
-        if (k == 0) x = v;
-        else if (k == 1) y = v;
-        else if (k == 2) z = v;
-        if (k >= 3) o[k] = v;
+    // twelve channels per pass, every load issued before the first store (a `load; store` loop over the channels waits for
+    // one memory round trip per channel: 9 of them for the 11.8 us this kernel took)
+    for (int k0 = 0; k0 < C; k0 += 12) {
+        float v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int k = k0 + u < C ? k0 + u : C - 1;
+            v[u] = channel_first ? src[(size_t)k * N + n] : src[(size_t)n * C + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int k = k0 + u;
+            if (k < C) {
+                if (k == 0) x = v[u];
+                else if (k == 1) y = v[u];
+                else if (k == 2) z = v[u];
+                else o[k] = v[u];
+            }
+        }
     }
     const float xr = x * c - y * s, yr = x * s + y * c;          // provider.py:78-81
     o[0] = xr;
@@ -58,9 +71,13 @@ __global__ __launch_bounds__(256) void seg_metrics_kernel(const float *__restric
         const float *row = logp + (size_t)r * C;
         int best = 0;
         float bv = row[0];
-        for (int k = 1; k < C; ++k) {                     // first maximum wins, like Tensor.max(1)[1] / np.argmax
-            const float v = row[k];
-            if (v > bv) { bv = v; best = k; }
+        for (int k0 = 1; k0 < C; k0 += 8) {               // eight classes per pass, loaded before the first compare
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[k0 + u < C ? k0 + u : C - 1];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)                   // first maximum wins, like Tensor.max(1)[1] / np.argmax
+                if (k0 + u < C && v[u] > bv) { bv = v[u]; best = k0 + u; }
         }
         const long long lab = target[r];
         atomicAdd(&cnt[1], 1u);
