@@ -367,7 +367,9 @@ def call(module, fn, inputs, before_replay=None):
             stats["eager"] += 1
             return fn(*inputs)
         try:
-            inst = _capture(module, fn, inputs, stable, params, want_backward)
+            from . import ops
+            with ops.capture_region():                  # no garbage collection inside a capture (ops.capture_region)
+                inst = _capture(module, fn, inputs, stable, params, want_backward)
         except RuntimeError as e:
             # a capture launches nothing and has no side effect on the model (parameters are swapped back, counters are
             # bumped by captured kernels only): whatever made it fail, the eager call is still right.  The signature is

@@ -503,6 +503,36 @@ def group_points(xyz, new_xyz, points, idx, pad_to=1, inv=None, with_skip=False)
 
 
 # ---------------------------------------------------------------------------------- interpolation
+# Graph captures of this package run inside capture_region(): Python's cyclic garbage collector is switched off for their
+# duration.  A collection that starts in the middle of a capture finalises whatever garbage is around -- an earlier trainer's
+# captured graphs, events, pool memory -- and HIP calls made from those finalisers are illegal while a stream is capturing:
+# the process aborts (seen twice in the full GPU suite, "Fatal Python error: Aborted ... Garbage-collecting" inside a capture).
+_CAPTURES_UNDERWAY = 0
+
+
+class capture_region:
+    def __enter__(self):
+        import gc
+        global _CAPTURES_UNDERWAY
+        gc.collect()                                  # what is garbage now goes before the capture, not inside it
+        self._was = gc.isenabled()
+        gc.disable()
+        _CAPTURES_UNDERWAY += 1
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        global _CAPTURES_UNDERWAY
+        _CAPTURES_UNDERWAY -= 1
+        if self._was and _CAPTURES_UNDERWAY == 0:
+            gc.enable()
+        return False
+
+
+def capturing():
+    return _CAPTURES_UNDERWAY > 0
+
+
 # PN2_LAB_SKIP_NN=<N>: lab switch -- 3-NN tables with at least N queries are computed once and then reused (WRONG results for
 # every later batch; it prices the launch for tools/ab_switch.sh, nothing else).  PN2_LAB_SKIP=inv,deep: the same for the
 # transposed index tables and for the sampling + ball queries of levels 2-4 (models/pointnet2_utils.py).

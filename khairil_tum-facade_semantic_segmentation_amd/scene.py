@@ -511,7 +511,9 @@ class BlockInferencer:
         # a captured graph must not be destroyed while a replay of it is still running (the geometry graph runs on the side
         # stream, behind the caller's back): wait for the device before the graphs go
         try:
-            self.torch.cuda.synchronize(self.dev)
+            from . import ops
+            if not ops.capturing():                               # (a device wait is illegal while a stream captures)
+                self.torch.cuda.synchronize(self.dev)
         except Exception:
             pass
 
@@ -557,6 +559,11 @@ class BlockInferencer:
             flat.copy_(self._pack(geo))
 
     def _capture(self):
+        from . import ops
+        with ops.capture_region():                      # no garbage collection inside a capture (ops.capture_region)
+            self._capture_graphs()
+
+    def _capture_graphs(self):
         torch = self.torch
         with torch.no_grad():
             for _ in range(2):                                   # lazy initialisations, eval coefficients (cached)

@@ -305,7 +305,8 @@ class SemSegTrainer:
         # a captured graph must not be destroyed while a replay of it is still running: the geometry graph of the last step
         # runs on the side stream for about a millisecond after step() has returned -- wait for the device before the graphs go
         try:
-            if self._g_fwd_bwd is not None:
+            from . import ops
+            if self._g_fwd_bwd is not None and not ops.capturing():       # (a device wait is illegal while a stream captures)
                 torch.cuda.synchronize()
         except Exception:
             pass
@@ -497,6 +498,11 @@ class SemSegTrainer:
         return loss
 
     def _capture(self, blocks_cf, target):
+        from . import ops
+        with ops.capture_region():                      # no garbage collection inside a capture (ops.capture_region)
+            self._capture_graphs(blocks_cf, target)
+
+    def _capture_graphs(self, blocks_cf, target):
         exchange = self._exchange()
         mlp.ensure_momentum_words(self.model)                   # outside the graph: replays then follow set_bn_momentum()
         head.ensure_ticket_words(blocks_cf.device)
