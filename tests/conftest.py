@@ -12,6 +12,11 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("PN2_TEST_GC_STRESS") == "1":
+        # stress: the cyclic collector runs after every few allocations -- a finaliser that must not run inside a graph
+        # capture (ops.capture_region) shows at once instead of once in ten runs
+        import gc
+        gc.set_threshold(20, 1, 1)
 
 
 def load_golden(name):
