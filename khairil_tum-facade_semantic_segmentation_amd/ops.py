@@ -514,7 +514,8 @@ class capture_region:
     def __enter__(self):
         import gc
         global _CAPTURES_UNDERWAY
-        gc.collect()                                  # what is garbage now goes before the capture, not inside it
+        if os.environ.get("PN2_LAB_NO_COLLECT_BEFORE_CAPTURE", "0") != "1":      # (lab: A/B of this collection)
+            gc.collect()                              # what is garbage now goes before the capture, not inside it
         self._was = gc.isenabled()
         gc.disable()
         _CAPTURES_UNDERWAY += 1

@@ -1,0 +1,5 @@
+one() { env "$@" timeout -k 10 300 python bench.py --drop-in --steps 100 --warmup 8 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])"; }
+for i in 1 2 3; do
+  echo "default (garbage collected before every capture)   $(one PN2_NOP=0)"
+  echo "PN2_LAB_NO_COLLECT_BEFORE_CAPTURE=1                $(one PN2_LAB_NO_COLLECT_BEFORE_CAPTURE=1)"
+done
