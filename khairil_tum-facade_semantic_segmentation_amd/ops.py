@@ -516,6 +516,9 @@ class capture_region:
         global _CAPTURES_UNDERWAY
         if os.environ.get("PN2_LAB_NO_COLLECT_BEFORE_CAPTURE", "0") != "1":      # (lab: A/B of this collection)
             gc.collect()                              # what is garbage now goes before the capture, not inside it
+            if os.environ.get("PN2_LAB_EMPTY_CACHE_BEFORE_CAPTURE", "0") == "1" and torch.cuda.is_available():
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
         self._was = gc.isenabled()
         gc.disable()
         _CAPTURES_UNDERWAY += 1
