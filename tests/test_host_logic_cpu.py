@@ -199,3 +199,35 @@ def test_module_graph_signatures_on_cpu():
     assert graphed._use_count(t) == base + 1
     del v
     assert graphed._use_count(t) == base
+
+
+def test_capture_region_keeps_the_collector_out_of_a_capture():
+    """ops.capture_region: garbage is collected before the region, the cyclic collector is off inside (nested regions
+    included) and back on behind the outermost one -- also when the body raises; destructors ask ops.capturing()."""
+    import gc
+    import weakref
+    from khairil_tum_facade_semantic_segmentation_amd import ops
+
+    class Node:
+        pass
+    a = Node(); a.self = a                                   # a reference cycle: only the collector frees it
+    w = weakref.ref(a)
+    del a
+    assert gc.isenabled() and not ops.capturing()
+    with ops.capture_region():
+        assert w() is None                                   # collected in front of the region
+        assert not gc.isenabled() and ops.capturing()
+        b = Node(); b.self = b
+        wb = weakref.ref(b)
+        del b
+        with ops.capture_region():
+            assert not gc.isenabled()
+        assert not gc.isenabled() and ops.capturing()
+        assert wb() is not None                              # nothing is finalised inside
+    assert gc.isenabled() and not ops.capturing()
+    try:
+        with ops.capture_region():
+            raise RuntimeError("capture failed")
+    except RuntimeError:
+        pass
+    assert gc.isenabled() and not ops.capturing()
