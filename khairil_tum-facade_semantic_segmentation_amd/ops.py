@@ -514,7 +514,8 @@ class capture_region:
     def __enter__(self):
         import gc
         global _CAPTURES_UNDERWAY
-        if os.environ.get("PN2_LAB_NO_COLLECT_BEFORE_CAPTURE", "0") != "1":      # (lab: A/B of this collection)
+        # (a nested region -- a capture inside a capture -- must not collect: it IS inside a capture)
+        if _CAPTURES_UNDERWAY == 0 and os.environ.get("PN2_LAB_NO_COLLECT_BEFORE_CAPTURE", "0") != "1":   # (lab: A/B of it)
             gc.collect()                              # what is garbage now goes before the capture, not inside it
             if os.environ.get("PN2_LAB_EMPTY_CACHE_BEFORE_CAPTURE", "0") == "1" and torch.cuda.is_available():
                 torch.cuda.synchronize()
